@@ -1,0 +1,347 @@
+"""CPU oracle for the fs-nerf ray-rendering hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file restates, with plain PyTorch CPU ops, the arithmetic of the reference
+(a-lemus96/fs-nerf) for the path  get_rays -> sampling -> positional encoding ->
+NeRF MLP -> volume integration.  It exists so that `tests/`, `__graft_entry__.smoke()`
+and the `cpu_baseline` leg of `bench.py` can check / time the HIP path against it.
+Nothing under `fs-nerf_amd/` imports it; the product path fails loudly without the
+HIP library.
+
+Pinning status ("Oracle"):
+  * get_rays, to_ndc, get_chunks, posenc, nerf_forward are PINNED: they are checked
+    against golden vectors produced by importing the reference's own modules
+    (`tests/golden/make_golden.py`, fixtures `tests/golden/*.npz`).
+  * composite / rendering_packed follow nerfacc 0.5.3 (`environment.yaml:341`), which
+    is a third-party dependency NOT present under /root/reference.  Its published
+    algorithm is restated here and anchored on the reference's call sites
+    (`src/render/rendering.py:66-74, 89-96`).  PARITY UNPINNED for these.
+  * stratified_edges, sample_pdf, merge_edges, freq_mask are this build's own
+    definitions of what `north_star` asks for (fixed-count stratified sampling,
+    hierarchical 64+128 sampling, frequency mask); the reference has no such
+    code.  PARITY UNPINNED; with mask == 1 and one network they reduce to the
+    reference formulas.
+
+All functions take / return torch CPU tensors; `dtype` follows the inputs so the
+same code runs in float32 (parity oracle, CPU baseline) and float64 (truth for
+error budgets).
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+FLT_EPS = 1.1920928955078125e-07  # torch.finfo(torch.float32).eps
+
+
+# --------------------------------------------------------------------------- rays
+def get_rays(pose: Tensor, hwf: Tuple[int, int, float]) -> Tuple[Tensor, Tensor]:
+    """Pinhole rays in world space.  Follows `src/utils/utilities.py:36-82`.
+
+    pixel (h, w): d_cam = [(w - W/2)/f, -(h - H/2)/f, -1], normalised to unit length
+    (`:66-72`), rotated by pose[:3,:3] (`:75-78`); origin = pose[:3,-1] (`:80`).
+    No half-pixel offset.  Returns ([H,W,3], [H,W,3]).
+    """
+    H, W, focal = hwf
+    dt = torch.float32
+    pose = pose.to(dt)
+    ww = torch.arange(W, dtype=dt)[None, :].expand(H, W)
+    hh = torch.arange(H, dtype=dt)[:, None].expand(H, W)
+    d_cam = torch.stack([(ww - W * 0.5) / focal, -(hh - H * 0.5) / focal,
+                         -torch.ones(H, W, dtype=dt)], dim=-1)
+    d_cam = d_cam / torch.norm(d_cam, dim=-1, keepdim=True)
+    # d_w[k] = sum_c d_cam[c] * R[k, c]   (same reduction order as the reference)
+    d_w = torch.sum(d_cam[..., None, :] * pose[:3, :3], dim=-1)
+    o_w = pose[:3, -1].expand(d_w.shape)
+    return o_w, d_w
+
+
+def to_ndc(rays_o: Tensor, rays_d: Tensor, hwf, near: float) -> Tuple[Tensor, Tensor]:
+    """Forward-facing NDC warp.  Follows `src/utils/utilities.py:84-120`."""
+    H, W, focal = hwf
+    t = -(near + rays_o[..., 2]) / rays_d[..., 2]
+    o = rays_o + t[..., None] * rays_d
+    sx = -1.0 / (W / (2.0 * focal))
+    sy = -1.0 / (H / (2.0 * focal))
+    o0 = sx * o[..., 0] / o[..., 2]
+    o1 = sy * o[..., 1] / o[..., 2]
+    o2 = 1.0 + 2.0 * near / o[..., 2]
+    d0 = sx * (rays_d[..., 0] / rays_d[..., 2] - o[..., 0] / o[..., 2])
+    d1 = sy * (rays_d[..., 1] / rays_d[..., 2] - o[..., 1] / o[..., 2])
+    d2 = -2.0 * near / o[..., 2]
+    return torch.stack([o0, o1, o2], -1), torch.stack([d0, d1, d2], -1)
+
+
+def get_chunks(t: Tensor, chunksize: int):
+    """Row slices.  Follows `src/utils/utilities.py:122-134`."""
+    return [t[i:i + chunksize] for i in range(0, t.shape[0], chunksize)]
+
+
+def pose_from_spherical(radius: float, theta_deg: float, phi_deg: float) -> Tensor:
+    """Orbit pose.  Follows `src/nerfdata/datasets/blender.py:20-69`
+    (rot_phi(phi) @ rot_theta(theta) @ trans_t(radius)), float32 like the reference."""
+    th, ph = theta_deg / 180.0 * math.pi, phi_deg / 180.0 * math.pi
+    tr = torch.tensor([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, radius], [0, 0, 0, 1]], dtype=torch.float32)
+    rt = torch.tensor([[1, 0, 0, 0], [0, math.cos(th), -math.sin(th), 0],
+                       [0, math.sin(th), math.cos(th), 0], [0, 0, 0, 1]], dtype=torch.float32)
+    rp = torch.tensor([[math.cos(ph), -math.sin(ph), 0, 0], [math.sin(ph), math.cos(ph), 0, 0],
+                       [0, 0, 1, 0], [0, 0, 0, 1]], dtype=torch.float32)
+    return rp @ (rt @ tr)
+
+
+# ------------------------------------------------------------------- encoding
+def pe_freqs(n_freqs: int, log_space: bool) -> Tensor:
+    """Frequency bands.  Follows `src/core/models.py:31-34` (float32 values)."""
+    if log_space:
+        return 2.0 ** torch.linspace(0.0, n_freqs - 1, n_freqs)
+    return torch.linspace(2.0 ** 0.0, 2.0 ** (n_freqs - 1), n_freqs)
+
+
+def posenc(x: Tensor, n_freqs: int, log_space: bool, mask: Optional[Tensor] = None) -> Tensor:
+    """[x, sin(f0 x), cos(f0 x), sin(f1 x), ...] -> [N, d*(1+2n)].
+    Follows `src/core/models.py:28,37-39,50` (block order, x*freq before sin).
+    `mask` ([d*(1+2n)], optional) multiplies the encoded features: the build's
+    frequency mask (not in the reference; mask == 1 is the reference)."""
+    fr = pe_freqs(n_freqs, log_space).to(x.dtype)
+    parts = [x]
+    for k in range(n_freqs):
+        parts.append(torch.sin(x * fr[k]))
+        parts.append(torch.cos(x * fr[k]))
+    y = torch.cat(parts, dim=-1)
+    if mask is not None:
+        y = y * mask.to(y.dtype)
+    return y
+
+
+def freq_mask(d_in: int, n_freqs: int, ratio: float) -> Tensor:
+    """Build's definition (FreeNeRF-style linear schedule): band k gets
+    clamp(L*ratio - k, 0, 1); the identity block is always 1.  Layout = posenc layout."""
+    m = [torch.ones(d_in)]
+    for k in range(n_freqs):
+        v = min(max(n_freqs * ratio - k, 0.0), 1.0)
+        m.append(torch.full((2 * d_in,), v))
+    return torch.cat(m).to(torch.float32)
+
+
+# ------------------------------------------------------------------------ MLP
+def nerf_forward(sd: Dict[str, Tensor], x: Tensor, dirs: Optional[Tensor], *,
+                 n_layers: int, skip: Sequence[int], n_freqs: int, n_freqs_dir: int,
+                 log_space: bool = True, log_space_dir: Optional[bool] = None,
+                 pos_mask: Optional[Tensor] = None, dir_mask: Optional[Tensor] = None) -> Tensor:
+    """NeRF MLP forward from a reference-format state_dict.
+    Follows `src/core/models.py:111-143`: relu(layer_i(h)); after layer i in `skip`
+    h = cat([h, x_in]); sigma head without activation; connection (no activation);
+    cat([feat, dir_enc]); relu(branch); sigmoid(rgb); returns [N,1] or [N,4]=[rgb,sigma]."""
+    if log_space_dir is None:
+        log_space_dir = log_space
+    dt = x.dtype
+    W = lambda k: sd[k].to(dt)
+    x_in = posenc(x, n_freqs, log_space, pos_mask)
+    h = x_in
+    for i in range(n_layers):
+        h = torch.relu(h @ W(f"layers.{i}.weight").T + W(f"layers.{i}.bias"))
+        if i in skip:
+            h = torch.cat([h, x_in], dim=-1)
+    sigma = h @ W("sigma.weight").T + W("sigma.bias")
+    if dirs is None:
+        return sigma
+    f = h @ W("connection.weight").T + W("connection.bias")
+    d_in = posenc(dirs, n_freqs_dir, log_space_dir, dir_mask)
+    f = torch.cat([f, d_in], dim=-1)
+    f = torch.relu(f @ W("branch.weight").T + W("branch.bias"))
+    rgb = torch.sigmoid(f @ W("rgb.weight").T + W("rgb.bias"))
+    return torch.cat([rgb, sigma], dim=-1)
+
+
+def init_nerf_state_dict(n_layers: int, d_hidden: int, skip: Sequence[int], n_freqs: int,
+                         n_freqs_dir: int, seed: int, d_pos: int = 3, d_dir: int = 3) -> Dict[str, Tensor]:
+    """Default nn.Linear init, created in the reference's construction order
+    (`src/core/models.py:96-108`: layers[1..], then layers[0], sigma, connection, branch, rgb)
+    so that torch.manual_seed(seed) reproduces the reference's parameters bit for bit."""
+    from torch import nn
+    torch.manual_seed(seed)
+    d_pe, d_de = d_pos * (1 + 2 * n_freqs), d_dir * (1 + 2 * n_freqs_dir)
+    hidden = [nn.Linear(d_hidden + d_pe, d_hidden) if i in skip else nn.Linear(d_hidden, d_hidden)
+              for i in range(n_layers - 1)]
+    first = nn.Linear(d_pe, d_hidden)
+    mods = {"sigma": nn.Linear(d_hidden, 1), "connection": nn.Linear(d_hidden, d_hidden),
+            "branch": nn.Linear(d_hidden + d_de, d_hidden // 2), "rgb": nn.Linear(d_hidden // 2, 3)}
+    sd = {}
+    for i, m in enumerate([first] + hidden):
+        sd[f"layers.{i}.weight"], sd[f"layers.{i}.bias"] = m.weight.detach().clone(), m.bias.detach().clone()
+    for k, m in mods.items():
+        sd[f"{k}.weight"], sd[f"{k}.bias"] = m.weight.detach().clone(), m.bias.detach().clone()
+    return sd
+
+
+# -------------------------------------------------------------------- sampling
+def stratified_edges(near: float, far: float, n_samples: int, n_rays: int,
+                     u: Optional[Tensor] = None, dtype=torch.float32) -> Tensor:
+    """Build's definition of the fixed-count sampler that fills the reference's
+    `estimator.sampling` slot (`src/render/rendering.py:66-74`).  Returns S+1 sorted interval
+    edges per ray, [R, S+1]; interval i = [e_i, e_{i+1}], sample position = its midpoint
+    (`rendering.py:61`).  step = (far-near)/S.
+      u is None            -> e_i = near + i*step                     (stratified=False)
+      u shape [R] / [R,1]  -> e_i = near + (i + u_r)*step             (one shift per ray: the
+                              nerfacc `stratified=True` behaviour the reference trains with)
+      u shape [R, S+1]     -> per-edge jitter inside [mid_{i-1}, mid_i] (mip-NeRF style):
+                              lo_i = near + max(i-0.5, 0)*step, hi_i = near + min(i+0.5, S)*step,
+                              e_i = lo_i + (hi_i - lo_i)*u_i
+    """
+    S = n_samples
+    step = torch.tensor((far - near) / S, dtype=dtype)
+    i = torch.arange(S + 1, dtype=dtype)[None, :]
+    nr = torch.tensor(near, dtype=dtype)
+    if u is None:
+        return (nr + i * step).expand(n_rays, S + 1).contiguous()
+    u = u.to(dtype)
+    if u.numel() == n_rays:
+        return nr + (i + u.reshape(n_rays, 1)) * step
+    assert u.shape == (n_rays, S + 1)
+    lo = nr + torch.clamp(i - 0.5, min=0.0) * step
+    hi = nr + torch.clamp(i + 0.5, max=float(S)) * step
+    return lo + (hi - lo) * u
+
+
+def edges_to_packed(edges: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """[R,S+1] edges -> nerfacc-style packed (ray_indices int64 [N], t_starts [N], t_ends [N])."""
+    R, S1 = edges.shape
+    ri = torch.arange(R, dtype=torch.int64)[:, None].expand(R, S1 - 1).reshape(-1)
+    return ri, edges[:, :-1].reshape(-1), edges[:, 1:].reshape(-1)
+
+
+def sample_pdf(edges: Tensor, weights: Tensor, n_importance: int, u: Optional[Tensor] = None) -> Tensor:
+    """Inverse-CDF importance sampling (NeRF-paper `sample_pdf`, restated for interval edges).
+    edges [R,S+1], weights [R,S] -> new t values [R,n_importance].
+    pdf = (max(w,0)+1e-5)/sum; cdf = [0, cumsum(pdf)]; u = linspace(0,1,n) if None (det) else
+    given [R,n]; idx = searchsorted(cdf, u, right=True); below = max(idx-1,0), above = min(idx,S);
+    denom = cdf[above]-cdf[below] (1 if < 1e-5); t = e_below + (u-cdf_below)/denom*(e_above-e_below).
+    The clamp max(w,0) is the build's addition: the reference network emits raw, possibly
+    negative sigma (`models.py:127`), which would make the cdf non-monotone."""
+    R, S = weights.shape
+    dt = edges.dtype
+    w = torch.clamp(weights, min=0.0) + 1e-5
+    pdf = w / torch.sum(w, dim=-1, keepdim=True)
+    cdf = torch.cat([torch.zeros(R, 1, dtype=dt), torch.cumsum(pdf, dim=-1)], dim=-1)
+    if u is None:
+        u = torch.linspace(0.0, 1.0, n_importance, dtype=dt)[None, :].expand(R, n_importance)
+    u = u.contiguous().to(dt)
+    idx = torch.searchsorted(cdf.contiguous(), u, right=True)
+    below = torch.clamp(idx - 1, min=0)
+    above = torch.clamp(idx, max=S)
+    c0, c1 = torch.gather(cdf, 1, below), torch.gather(cdf, 1, above)
+    e0, e1 = torch.gather(edges, 1, below), torch.gather(edges, 1, above)
+    denom = c1 - c0
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    return e0 + (u - c0) / denom * (e1 - e0)
+
+
+def merge_edges(edges: Tensor, t_new: Tensor) -> Tensor:
+    """Sorted union of coarse edges [R,S+1] and importance samples [R,n] -> [R,S+1+n]."""
+    return torch.sort(torch.cat([edges, t_new], dim=-1), dim=-1).values
+
+
+# ----------------------------------------------------------------- compositing
+def composite(sigmas: Tensor, rgbs: Tensor, t_starts: Tensor, t_ends: Tensor,
+              bkgd: Optional[Tensor] = None):
+    """Dense [R,S] volume integration = nerfacc 0.5.3 `volrend.rendering` arithmetic
+    (call site `src/render/rendering.py:89-96`; nerfacc source NOT in /root/reference — PARITY
+    UNPINNED): dt = t1-t0; alpha = 1-exp(-sigma dt); T = exp(-exclusive_cumsum(sigma dt));
+    w = T alpha; colors = sum w rgb; opacity = sum w; depth = sum w (t0+t1)/2 / max(opacity, eps);
+    colors += bkgd (1-opacity).  No clamp on sigma (the reference net emits raw sigma).
+    Returns colors [R,3], opacity [R,1], depth [R,1], extras dict with [R,S] entries."""
+    sdt = sigmas * (t_ends - t_starts)
+    alphas = 1.0 - torch.exp(-sdt)
+    excl = torch.cumsum(sdt, dim=-1) - sdt
+    trans = torch.exp(-excl)
+    w = trans * alphas
+    colors = torch.sum(w[..., None] * rgbs, dim=-2)
+    opacity = torch.sum(w, dim=-1, keepdim=True)
+    depth = torch.sum(w * (t_starts + t_ends) / 2.0, dim=-1, keepdim=True)
+    depth = depth / torch.clamp(opacity, min=FLT_EPS)
+    if bkgd is not None:
+        colors = colors + bkgd.to(colors.dtype) * (1.0 - opacity)
+    extras = {"weights": w, "alphas": alphas, "trans": trans, "sigmas": sigmas, "rgbs": rgbs}
+    return colors, opacity, depth, extras
+
+
+def rendering_packed(t_starts: Tensor, t_ends: Tensor, ray_indices: Tensor, n_rays: int,
+                     rgb_sigma_fn: Callable, render_bkgd: Optional[Tensor] = None):
+    """Packed / variable-length form with the nerfacc call signature used at
+    `src/render/rendering.py:89-96` (samples of a ray are contiguous and sorted by ray).
+    Raises AssertionError on the shape violations nerfacc asserts (caught at `rendering.py:97`)."""
+    rgbs, sigmas = rgb_sigma_fn(t_starts, t_ends, ray_indices)
+    assert rgbs.shape[-1] == 3, f"rgbs must have 3 channels, got {rgbs.shape}"
+    assert sigmas.shape == t_starts.shape, f"sigmas must have shape of (N,)! Got {sigmas.shape}"
+    N = t_starts.shape[0]
+    dt = t_starts.dtype
+    sdt = sigmas * (t_ends - t_starts)
+    alphas = 1.0 - torch.exp(-sdt)
+    csum = torch.cumsum(sdt, dim=0)
+    # exclusive sum restarted at every ray boundary
+    first = torch.ones(N, dtype=torch.bool)
+    if N > 1:
+        first[1:] = ray_indices[1:] != ray_indices[:-1]
+    start_val = torch.zeros(N, dtype=dt)
+    seg_start_csum = (csum - sdt)[first]
+    seg_id = torch.cumsum(first.to(torch.int64), 0) - 1
+    if N > 0:
+        start_val = seg_start_csum[seg_id]
+    trans = torch.exp(-((csum - sdt) - start_val))
+    w = trans * alphas
+    colors = torch.zeros(n_rays, 3, dtype=dt).index_add_(0, ray_indices, w[:, None] * rgbs)
+    opacity = torch.zeros(n_rays, 1, dtype=dt).index_add_(0, ray_indices, w[:, None])
+    depth = torch.zeros(n_rays, 1, dtype=dt).index_add_(0, ray_indices, (w * (t_starts + t_ends) / 2.0)[:, None])
+    depth = depth / torch.clamp(opacity, min=FLT_EPS)
+    if render_bkgd is not None:
+        colors = colors + render_bkgd.to(dt) * (1.0 - opacity)
+    extras = {"weights": w, "alphas": alphas, "trans": trans, "sigmas": sigmas, "rgbs": rgbs}
+    return colors, opacity, depth, extras
+
+
+# ------------------------------------------------------------- whole hot path
+def render_rays_oracle(rays_o: Tensor, rays_d: Tensor, sd_coarse: Dict[str, Tensor],
+                       sd_fine: Optional[Dict[str, Tensor]], cfg: dict, *, near: float, far: float,
+                       n_samples: int, n_importance: int = 0, u: Optional[Tensor] = None,
+                       u_fine: Optional[Tensor] = None, white_bkgd: bool = False,
+                       pos_mask: Optional[Tensor] = None, dir_mask: Optional[Tensor] = None):
+    """The whole path in the reference's operator order (`src/render/rendering.py:58-107`):
+      1. intervals from `stratified_edges` (fills the `estimator.sampling` slot, `:66-74`);
+      2. density-only pass sigma_fn: x = o + d*(t0+t1)/2; sigma = model(x)       (`:58-64`)
+         -> weights (same alpha/T arithmetic as step 4)        [only if n_importance > 0]
+      3. `sample_pdf` + sorted union -> S+n_importance intervals [only if n_importance > 0]
+      4. full pass rgb_sigma_fn: out = model(x, d); rgbs = out[:, :3]; sigmas = out[:, -1]
+         (`:76-84`), `composite` with bkgd = white_bkgd*ones(3) (`:86, 89-96`);
+      5. t_vals = (t0+t1)/2 (`:105`).
+    `sd_fine is None` uses one network for both passes, as the reference does.
+    Returns ((rgb [R,3], opacity [R,1], depth [R,1], extras), ray_indices [N], t_vals [N]);
+    extras additionally holds "edges" [R,S'+1] and, when hierarchical, "weights_coarse" [R,S]."""
+    R = rays_o.shape[0]
+    dt = rays_o.dtype
+    mk = dict(n_layers=cfg["n_layers"], skip=cfg["skip"], n_freqs=cfg["n_freqs"],
+              n_freqs_dir=cfg["n_freqs_dir"], log_space=cfg.get("log_space", True),
+              pos_mask=pos_mask, dir_mask=dir_mask)
+    edges = stratified_edges(near, far, n_samples, R, u, dtype=dt)
+    w_coarse = None
+    if n_importance > 0:
+        t0, t1 = edges[:, :-1], edges[:, 1:]
+        x = rays_o[:, None, :] + rays_d[:, None, :] * (t0 + t1)[..., None] / 2.0
+        sig = nerf_forward(sd_coarse, x.reshape(-1, 3), None, **mk).reshape(R, n_samples)
+        sdt = sig * (t1 - t0)
+        w_coarse = torch.exp(-(torch.cumsum(sdt, -1) - sdt)) * (1.0 - torch.exp(-sdt))
+        edges = merge_edges(edges, sample_pdf(edges, w_coarse, n_importance, u_fine))
+    sd = sd_fine if sd_fine is not None else sd_coarse
+    t0, t1 = edges[:, :-1], edges[:, 1:]
+    S = t0.shape[1]
+    x = rays_o[:, None, :] + rays_d[:, None, :] * (t0 + t1)[..., None] / 2.0
+    d = rays_d[:, None, :].expand(R, S, 3)
+    out = nerf_forward(sd, x.reshape(-1, 3), d.reshape(-1, 3), **mk).reshape(R, S, 4)
+    bk = float(white_bkgd) * torch.ones(3, dtype=dt)
+    colors, opacity, depth, extras = composite(out[..., 3], out[..., :3], t0, t1, bk)
+    extras["edges"] = edges
+    if w_coarse is not None:
+        extras["weights_coarse"] = w_coarse
+    ri, ts, te = edges_to_packed(edges)
+    return (colors, opacity, depth, extras), ri, (ts + te) / 2.0
