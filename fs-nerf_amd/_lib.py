@@ -1,0 +1,86 @@
+"""ctypes binding of libfsnerf_hip.so (C-ABI: include/fsnerf_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails, a RuntimeError
+is raised.  PyTorch is only used for device memory and streams."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libfsnerf_hip.so")
+
+FSN_PREC_BF16X3 = 0
+FSN_PREC_BF16 = 1
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("d_hidden", C.c_int32), ("skip_mask", C.c_uint32),
+                ("n_freqs_pos", C.c_int32), ("n_freqs_dir", C.c_int32),
+                ("freqs_pos", C.c_float * 16), ("freqs_dir", C.c_float * 16)]
+
+
+class RenderArgs(C.Structure):
+    _fields_ = [("rays_o", C.c_void_p), ("rays_d", C.c_void_p), ("R", C.c_int64),
+                ("near", C.c_float), ("far", C.c_float), ("S", C.c_int32), ("n_imp", C.c_int32),
+                ("u_mode", C.c_int32), ("u", C.c_void_p), ("u_fine", C.c_void_p),
+                ("pos_mask", C.c_void_p), ("dir_mask", C.c_void_p), ("bkgd", C.c_float * 3),
+                ("colors", C.c_void_p), ("opacity", C.c_void_p), ("depth", C.c_void_p),
+                ("weights", C.c_void_p), ("alphas", C.c_void_p), ("trans", C.c_void_p),
+                ("sigmas", C.c_void_p), ("rgbs", C.c_void_p), ("edges_out", C.c_void_p),
+                ("weights_coarse", C.c_void_p)]
+
+
+_vp, _i, _i64, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
+_PD = C.POINTER(MlpDesc)
+
+# name -> (restype, argtypes); every symbol declared in include/fsnerf_hip.h
+SIGNATURES = {
+    "fsn_version": (_i, []),
+    "fsn_last_error": (C.c_char_p, []),
+    "fsn_device_cus": (_i, []),
+    "fsn_get_rays": (_i, [_vp, _i, _i, _d, _i, _i, _vp, _vp, _vp]),
+    "fsn_to_ndc": (_i, [_vp, _vp, _i64, _i, _i, _d, _d, _vp, _vp, _vp]),
+    "fsn_posenc_fwd": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
+    "fsn_stratified_edges": (_i, [_f, _f, _i, _i64, _vp, _i, _vp, _vp]),
+    "fsn_edges_to_packed": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp]),
+    "fsn_sample_pdf_merge": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
+    "fsn_composite_fwd": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fsn_composite_packed_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fsn_mlp_blob_bytes": (_i64, [_PD, _i]),
+    "fsn_mlp_pack": (_i, [_PD, _i, _vp, _vp, _vp, _vp]),
+    "fsn_mlp_pack_host": (_i, [_PD, _i, _vp, _vp, _vp]),
+    "fsn_mlp_fwd": (_i, [_PD, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "fsn_render_rays_fused": (_i, [_PD, _i, _vp, _vp, C.POINTER(RenderArgs), _vp]),
+}
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j4"] + (["-B"] if force else [])
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libfsnerf_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no CPU fallback for the HIP path)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().fsn_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")

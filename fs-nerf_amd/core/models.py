@@ -1,0 +1,101 @@
+"""Host-side mirror of the reference's `core/models.py` call surface, backed by HIP kernels.
+
+  PositionalEncoder(d_input, n_freqs, log_space=False).forward(x)   (src/core/models.py:10-50)
+  NeRF(d_pos, d_dir, n_layers, d_hidden, skip, pos_fn=..., dir_fn=...).forward(x, dirs=None)
+                                                                      (src/core/models.py:53-143)
+Parameters are ordinary nn.Linear modules under the reference's attribute names, so a reference
+`state_dict()` loads unchanged (keys layers.N.*, sigma.*, connection.*, branch.*, rgb.*).
+`forward` never touches them with torch ops: they are packed into the MFMA streaming layout
+(re-packed whenever a parameter's version counter changes) and the whole network runs in the
+fused kernel `fsn_mlp_fwd`.  Additions over the reference: an optional frequency mask
+(`set_freq_mask`) and the arithmetic mode (`precision`: "bf16x3" ~fp32 accuracy, "bf16" fast).
+"""
+from typing import Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from .. import _lib as L
+from .. import ops
+
+
+def _freqs(n_freqs: int, log_space: bool) -> Tensor:
+    # same expressions as the reference (models.py:31-34), evaluated by torch on the CPU once
+    if log_space:
+        return 2.0 ** torch.linspace(0.0, n_freqs - 1, n_freqs)
+    return torch.linspace(2.0 ** 0.0, 2.0 ** (n_freqs - 1), n_freqs)
+
+
+class PositionalEncoder(nn.Module):
+    def __init__(self, d_input: int, n_freqs: int, log_space: bool = False):
+        super().__init__()
+        self.d_input, self.n_freqs, self.log_space = d_input, n_freqs, log_space
+        self.d_output = d_input * (1 + 2 * n_freqs)
+        self.freqs = [float(f) for f in _freqs(n_freqs, log_space)] if n_freqs > 0 else []
+
+    def forward(self, x: Tensor, mask: Optional[Tensor] = None) -> Tensor:
+        return ops.posenc(x, self.freqs, mask)
+
+
+class NeRF(nn.Module):
+    PRECISIONS = {"bf16x3": L.FSN_PREC_BF16X3, "bf16": L.FSN_PREC_BF16}
+
+    def __init__(self, d_pos: int = 3, d_dir: int = 3, n_layers: int = 8, d_hidden: int = 256,
+                 skip: Tuple[int, ...] = (4,), precision: str = "bf16x3", **kwargs) -> None:
+        super().__init__()
+        if d_pos != 3 or d_dir != 3:
+            raise ValueError("the HIP path is built for 3-D positions and directions")
+        self.d_pos, self.d_dir, self.n_layers, self.d_hidden = d_pos, d_dir, n_layers, d_hidden
+        self.skip = tuple(skip)
+        self.pos_encoder = PositionalEncoder(d_pos, kwargs["pos_fn"]["n_freqs"], kwargs["pos_fn"]["log_space"])
+        self.dir_encoder = PositionalEncoder(d_dir, kwargs["dir_fn"]["n_freqs"], kwargs["dir_fn"]["log_space"])
+        d_pe, d_de = self.pos_encoder.d_output, self.dir_encoder.d_output
+        # construction order follows the reference (models.py:96-108) so that seeding
+        # torch's RNG reproduces its initial parameters
+        hidden = [nn.Linear(d_hidden + d_pe, d_hidden) if i in self.skip else nn.Linear(d_hidden, d_hidden)
+                  for i in range(n_layers - 1)]
+        self.layers = nn.ModuleList([nn.Linear(d_pe, d_hidden)] + hidden)
+        self.sigma = nn.Linear(d_hidden, 1)
+        self.connection = nn.Linear(d_hidden, d_hidden)
+        self.branch = nn.Linear(d_hidden + d_de, d_hidden // 2)
+        self.rgb = nn.Linear(d_hidden // 2, 3)
+        self.precision = precision
+        self.pos_mask: Optional[Tensor] = None
+        self.dir_mask: Optional[Tensor] = None
+        self._packed = None
+        self._packed_key = None
+
+    # -- additions -----------------------------------------------------------------
+    def set_freq_mask(self, pos_mask: Optional[Tensor], dir_mask: Optional[Tensor] = None) -> None:
+        """Frequency mask multiplied onto the encoded features ([d_pos*(1+2n)], [d_dir*(1+2m)])."""
+        self.pos_mask, self.dir_mask = pos_mask, dir_mask
+
+    def _tensors(self):
+        mods = list(self.layers) + [self.sigma, self.connection, self.branch, self.rgb]
+        return [m.weight for m in mods], [m.bias for m in mods]
+
+    def packed(self) -> ops.PackedMLP:
+        """Weights in the MFMA streaming layout; re-packed when any parameter changed."""
+        ws, bs = self._tensors()
+        key = (self.precision, ws[0].device) + tuple((t.data_ptr(), t._version) for t in ws + bs)
+        if self._packed is None or key != self._packed_key:
+            desc = ops.make_desc(self.n_layers, self.d_hidden, self.skip, self.pos_encoder.freqs,
+                                 self.dir_encoder.freqs)
+            if self._packed is None or self._packed.prec != self.PRECISIONS[self.precision] \
+                    or self._packed.blob.device != ws[0].device:
+                self._packed = ops.PackedMLP(desc, self.PRECISIONS[self.precision], ws[0].device)
+            self._packed.pack(ws, bs)
+            self._packed_key = key
+        return self._packed
+
+    def _mask(self, m: Optional[Tensor], dev) -> Optional[Tensor]:
+        return None if m is None else m.to(dev, torch.float32)
+
+    # -- reference surface ---------------------------------------------------------
+    def forward(self, x: Tensor, dirs: Optional[Tensor] = None) -> Tensor:
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "NeRF.forward: the backward kernels are not built yet (SURVEY.md 8 f1); call under "
+                "torch.no_grad() or model.eval() - there is no PyTorch fallback by design")
+        dev = x.device
+        return ops.mlp_fwd(self.packed(), x, dirs, self._mask(self.pos_mask, dev), self._mask(self.dir_mask, dev))

@@ -1,0 +1,259 @@
+// mlp.hip — weight packing (host + device) and the standalone NeRF.forward kernel.
+// reference: src/core/models.py:53-143 (NeRF), state_dict layout SURVEY.md 8a (a5).
+#include "common.hpp"
+#include "mlp_dev.hpp"
+#include "mlp_layout.hpp"
+
+#include <cstring>
+#include <vector>
+
+namespace fsn {
+
+// ------------------------------------------------------------------ packing
+struct PackArgs {
+  NetGeom G;
+  const float* W[kMaxLayers + 4];  // layers.0.., sigma, connection, branch, rgb (reference order)
+  const float* b[kMaxLayers + 4];
+  int32_t n_layers, d_hidden, prec;
+  uint32_t skip_mask;
+  int32_t n_freqs_pos, n_freqs_dir;
+  float freqs_pos[16], freqs_dir[16];
+};
+
+// weight index (state_dict order) of GEMM g (kernel order: hidden 0..L-1, connection, branch)
+FSN_HD int gemm_to_sd(int g, int L) { return g < L ? g : g + 1; }  // skips "sigma" at index L
+
+// One 16-byte piece = 8 bf16 of (unit, part hi/lo, lane).  Shared by host and device packers.
+FSN_HD void pack_piece(const PackArgs& a, int64_t piece, uint16_t out8[8]) {
+  const int ub = unit_bytes(a.prec);
+  const int ppu = ub / 16;  // pieces per unit
+  const int unit = (int)(piece / ppu);
+  const int rem = (int)(piece - (int64_t)unit * ppu);
+  const int part = rem >> 6, lane = rem & 63;
+  for (int j = 0; j < 8; ++j) out8[j] = 0;
+  if (unit >= a.G.units_total) return;  // tail padding of the last phase
+  int g = 0;
+  while (g + 1 < a.G.n_gemm && a.G.g[g + 1].unit0 <= unit) ++g;
+  const LayerGeom& Lg = a.G.g[g];
+  const int ks_tot = Lg.ks_act + Lg.ks_enc;
+  const int lu = unit - Lg.unit0;
+  const int t = lu / ks_tot, ks = lu - t * ks_tot;
+  const int r = lane & 31, h = lane >> 5;
+  const float* W = a.W[gemm_to_sd(g, a.n_layers)];
+  const int row = 32 * t + r;
+  for (int j = 0; j < 8; ++j) {
+    const int col = unit_src_col(Lg, ks, h, j);
+    if (col < 0) continue;
+    const float w = W[(int64_t)row * Lg.ld + col];
+    const uint16_t hi = bf16_rne(w);
+    out8[j] = part == 0 ? hi : bf16_rne(w - bf16_to_f32(hi));
+  }
+}
+
+// aux float `i` of the blob
+FSN_HD float aux_value(const PackArgs& a, int i) {
+  const int D = a.d_hidden, L = a.n_layers;
+  const int blk = i / D, off = i - blk * D;
+  if (blk < L) return a.b[blk][off];                          // hidden biases
+  if (blk == L) return a.b[L + 1][off];                       // connection bias
+  if (blk == L + 1) return off < D / 2 ? a.b[L + 2][off] : 0.f;  // branch bias
+  if (blk == L + 2) return a.W[L][off];                       // sigma.weight [1,D]
+  if (blk == L + 3 || blk == L + 4) {                         // rgb.weight [3,D/2]
+    const int k = i - (L + 3) * D;
+    return k < 3 * (D / 2) ? a.W[L + 3][k] : 0.f;
+  }
+  const int m = i - (L + 5) * D;
+  if (m == 0) return a.b[L][0];                 // sigma.bias
+  if (m >= 1 && m <= 3) return a.b[L + 3][m - 1];  // rgb.bias
+  if (m >= 4 && m < 20) return a.freqs_pos[m - 4];
+  if (m >= 20 && m < 36) return a.freqs_dir[m - 20];
+  return 0.f;
+}
+
+FSN_HD void header_words(const PackArgs& a, uint32_t hw[64]) {
+  for (int i = 0; i < 64; ++i) hw[i] = 0;
+  hw[0] = kBlobMagic; hw[1] = 1; hw[2] = (uint32_t)a.prec; hw[3] = (uint32_t)a.n_layers;
+  hw[4] = (uint32_t)a.d_hidden; hw[5] = a.skip_mask; hw[6] = (uint32_t)a.n_freqs_pos;
+  hw[7] = (uint32_t)a.n_freqs_dir; hw[8] = (uint32_t)a.G.units_total; hw[9] = (uint32_t)a.G.nph_full;
+  hw[10] = (uint32_t)a.G.nph_density; hw[11] = (uint32_t)a.G.aux_off; hw[12] = (uint32_t)a.G.aux_floats;
+  hw[13] = (uint32_t)a.G.stream_off; hw[14] = (uint32_t)(a.G.total_bytes & 0xffffffffu);
+}
+
+__global__ void k_pack_stream(PackArgs a, char* __restrict__ blob, int64_t n_pieces) {
+  const int64_t piece = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (piece >= n_pieces) return;
+  uint16_t o[8];
+  pack_piece(a, piece, o);
+  uint4 v;
+  v.x = o[0] | ((uint32_t)o[1] << 16);
+  v.y = o[2] | ((uint32_t)o[3] << 16);
+  v.z = o[4] | ((uint32_t)o[5] << 16);
+  v.w = o[6] | ((uint32_t)o[7] << 16);
+  *reinterpret_cast<uint4*>(blob + a.G.stream_off + piece * 16) = v;
+}
+
+__global__ void k_pack_aux(PackArgs a, char* __restrict__ blob) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 64) {
+    uint32_t hw[64];
+    header_words(a, hw);
+    uint32_t w = 0;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) w = (k == i) ? hw[k] : w;
+    reinterpret_cast<uint32_t*>(blob)[i] = w;
+  }
+  if (i < a.G.aux_floats) reinterpret_cast<float*>(blob + a.G.aux_off)[i] = aux_value(a, i);
+}
+
+static int fill_pack_args(const fsn_mlp_desc* d, int prec, const float* const* W, const float* const* b,
+                          PackArgs& a) {
+  FSN_REQUIRE(d && W && b, FSN_E_INVALID, "mlp_pack: null pointer");
+  const char* why;
+  const int rc = build_geom(*d, prec, a.G, &why);
+  FSN_REQUIRE(rc == FSN_OK, rc, "mlp_pack: %s", why);
+  for (int i = 0; i < d->n_layers + 4; ++i) {
+    FSN_REQUIRE(W[i] && b[i], FSN_E_INVALID, "mlp_pack: null weight/bias %d", i);
+    a.W[i] = W[i];
+    a.b[i] = b[i];
+  }
+  a.n_layers = d->n_layers; a.d_hidden = d->d_hidden; a.prec = prec; a.skip_mask = d->skip_mask;
+  a.n_freqs_pos = d->n_freqs_pos; a.n_freqs_dir = d->n_freqs_dir;
+  std::memcpy(a.freqs_pos, d->freqs_pos, sizeof(a.freqs_pos));
+  std::memcpy(a.freqs_dir, d->freqs_dir, sizeof(a.freqs_dir));
+  return FSN_OK;
+}
+
+static NetParams make_net_params(const fsn_mlp_desc& d, const NetGeom& G, const void* blob) {
+  NetParams p;
+  p.blob = static_cast<const char*>(blob);
+  p.aux_off = (int32_t)G.aux_off; p.aux_floats = G.aux_floats; p.stream_off = (int32_t)G.stream_off;
+  p.nph_density = G.nph_density; p.nph_full = G.nph_full;
+  p.n_layers = d.n_layers; p.skip_mask = d.skip_mask;
+  p.n_freqs_pos = d.n_freqs_pos; p.n_freqs_dir = d.n_freqs_dir;
+  return p;
+}
+
+// ------------------------------------------------------------------ NeRF.forward kernel
+struct MlpFwdArgs {
+  NetParams net;
+  const float* x;
+  const float* dirs;  // null -> density only
+  const float* pos_mask;
+  const float* dir_mask;
+  int64_t n;
+  float* out;
+};
+
+// Persistent workgroups; tile = 128 consecutive samples; wave w / lane (r,h) owns sample
+// 128*tile + 32*w + r.  LDS: [weight ring 64 KiB][aux + masks].
+template <int NT, int PREC, bool FULL>
+__global__ __launch_bounds__(256) void k_mlp_fwd(MlpFwdArgs a) {
+  __shared__ __attribute__((aligned(1024))) char smem[kRingBytes + (kAuxCapFloats + 96) * 4];
+  float* aux_lds = reinterpret_cast<float*>(smem + kRingBytes);
+  NetDev net;
+  load_net(a.net, a.pos_mask, a.dir_mask, aux_lds, net);
+  __syncthreads();
+  constexpr bool full = FULL;
+  const int64_t ntiles = (a.n + 127) / 128;
+  WStream st;
+  const char* sbase = a.net.blob + a.net.stream_off;
+  st.init(smem, nullptr, 0, 0, sbase, (uint32_t)(full ? a.net.nph_full : a.net.nph_density), 1);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t s = tile * 128 + wave * 32 + (lane & 31);
+    const int64_t sc = s < a.n ? s : a.n - 1;
+    const float px = a.x[3 * sc], py = a.x[3 * sc + 1], pz = a.x[3 * sc + 2];
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (full) { dx = a.dirs[3 * sc]; dy = a.dirs[3 * sc + 1]; dz = a.dirs[3 * sc + 2]; }
+    float sigma, rgb[3] = {0.f, 0.f, 0.f};
+    mlp_tile<NT, PREC, FULL>(st, net, px, py, pz, dx, dy, dz, sigma, rgb);
+    if (lane < 32 && s < a.n) {
+      if (full) {
+        f32x4 o = {rgb[0], rgb[1], rgb[2], sigma};
+        *reinterpret_cast<f32x4*>(a.out + 4 * s) = o;
+      } else {
+        a.out[s] = sigma;
+      }
+    }
+  }
+  st.drain();
+}
+
+template <int NT, int PREC>
+static int launch_mlp_fwd(const MlpFwdArgs& a, int cus, hipStream_t s) {
+  const int64_t ntiles = (a.n + 127) / 128;
+  const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
+  if (a.dirs) k_mlp_fwd<NT, PREC, true><<<grid, 256, 0, s>>>(a);
+  else k_mlp_fwd<NT, PREC, false><<<grid, 256, 0, s>>>(a);
+  FSN_LAUNCH_CHECK("k_mlp_fwd");
+  return FSN_OK;
+}
+
+}  // namespace fsn
+
+using namespace fsn;
+
+extern "C" int64_t fsn_mlp_blob_bytes(const fsn_mlp_desc* desc, int prec) {
+  FSN_REQUIRE(desc, FSN_E_INVALID, "fsn_mlp_blob_bytes: null desc");
+  NetGeom G;
+  const char* why;
+  const int rc = build_geom(*desc, prec, G, &why);
+  FSN_REQUIRE(rc == FSN_OK, rc, "fsn_mlp_blob_bytes: %s", why);
+  return G.total_bytes;
+}
+
+extern "C" int fsn_mlp_pack(const fsn_mlp_desc* desc, int prec, const float* const* weights, const float* const* biases,
+                            void* blob, fsn_stream_t stream) {
+  FSN_REQUIRE(blob, FSN_E_INVALID, "fsn_mlp_pack: null blob");
+  PackArgs a;
+  const int rc = fill_pack_args(desc, prec, weights, biases, a);
+  if (rc != FSN_OK) return rc;
+  const int64_t n_pieces = (int64_t)a.G.nph_full * kPhaseBytes / 16;
+  k_pack_stream<<<(unsigned)((n_pieces + 255) / 256), 256, 0, as_stream(stream)>>>(a, static_cast<char*>(blob), n_pieces);
+  FSN_LAUNCH_CHECK("k_pack_stream");
+  const int naux = a.G.aux_floats > 64 ? a.G.aux_floats : 64;
+  k_pack_aux<<<(unsigned)((naux + 255) / 256), 256, 0, as_stream(stream)>>>(a, static_cast<char*>(blob));
+  FSN_LAUNCH_CHECK("k_pack_aux");
+  return FSN_OK;
+}
+
+extern "C" int fsn_mlp_pack_host(const fsn_mlp_desc* desc, int prec, const float* const* weights,
+                                 const float* const* biases, void* blob_host) {
+  FSN_REQUIRE(blob_host, FSN_E_INVALID, "fsn_mlp_pack_host: null blob");
+  PackArgs a;
+  const int rc = fill_pack_args(desc, prec, weights, biases, a);
+  if (rc != FSN_OK) return rc;
+  char* blob = static_cast<char*>(blob_host);
+  std::memset(blob, 0, (size_t)a.G.total_bytes);
+  uint32_t hw[64];
+  header_words(a, hw);
+  std::memcpy(blob, hw, sizeof(hw));
+  float* aux = reinterpret_cast<float*>(blob + a.G.aux_off);
+  for (int i = 0; i < a.G.aux_floats; ++i) aux[i] = aux_value(a, i);
+  const int64_t n_pieces = (int64_t)a.G.nph_full * kPhaseBytes / 16;
+  uint16_t* sp = reinterpret_cast<uint16_t*>(blob + a.G.stream_off);
+  for (int64_t p = 0; p < n_pieces; ++p) pack_piece(a, p, sp + p * 8);
+  return FSN_OK;
+}
+
+extern "C" int fsn_mlp_fwd(const fsn_mlp_desc* desc, int prec, const void* blob, const float* x, const float* dirs,
+                           const float* pos_mask, const float* dir_mask, int64_t n, float* out, fsn_stream_t stream) {
+  FSN_REQUIRE(desc && n >= 0, FSN_E_INVALID, "fsn_mlp_fwd: bad arguments");
+  NetGeom G;
+  const char* why;
+  const int rc = build_geom(*desc, prec, G, &why);
+  FSN_REQUIRE(rc == FSN_OK, rc, "fsn_mlp_fwd: %s", why);
+  if (n == 0) return FSN_OK;
+  FSN_REQUIRE(blob && x && out, FSN_E_INVALID, "fsn_mlp_fwd: null pointer");
+  FSN_REQUIRE(G.aux_floats <= kAuxCapFloats, FSN_E_UNSUPPORTED, "fsn_mlp_fwd: network too deep for the LDS aux area");
+  const int cus = fsn_device_cus();
+  if (cus <= 0) return FSN_E_HIP;
+  MlpFwdArgs a{make_net_params(*desc, G, blob), x, dirs, pos_mask, dir_mask, n, out};
+  hipStream_t s = as_stream(stream);
+  if (desc->d_hidden == 256) {
+    return prec == FSN_PREC_BF16X3 ? launch_mlp_fwd<8, FSN_PREC_BF16X3>(a, cus, s)
+                                   : launch_mlp_fwd<8, FSN_PREC_BF16>(a, cus, s);
+  }
+  return prec == FSN_PREC_BF16X3 ? launch_mlp_fwd<4, FSN_PREC_BF16X3>(a, cus, s)
+                                 : launch_mlp_fwd<4, FSN_PREC_BF16>(a, cus, s);
+}

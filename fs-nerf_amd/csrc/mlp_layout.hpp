@@ -1,0 +1,156 @@
+// mlp_layout.hpp — the packed-weights blob: geometry shared by the host packer, the device
+// packer and the MFMA kernels.  (DESIGN.md "weight blob" describes this in prose.)
+//
+// The NeRF MLP (src/core/models.py:96-143) is evaluated TRANSPOSED on the matrix cores:
+//   H_out^T [features x samples] = W [out x in] . H_in^T [in x samples]
+// with v_mfma_f32_32x32x16_bf16: A = a 32(out) x 16(in) weight fragment, B = a 16(in) x 32
+// (samples) activation fragment, D = a 32(out) x 32(samples) fp32 accumulator tile whose
+// layout (column = lane&31 = sample, row = (reg&3)+8(reg>>2)+4(lane>>5) = out feature) is
+// exactly the B-operand layout of the next layer, so activations never leave registers.
+//
+// A "unit" is the A operand of one (layer, out-tile t, k-step ks): one 1-KiB fragment of the
+// bf16 high parts and (FSN_PREC_BF16X3) one 1-KiB fragment of the bf16 low parts, lane-linear
+// (lane l owns bytes [16 l, 16 l + 16)).  Units are stored in the order the kernel consumes
+// them (layer, then out-tile, then k-step) and streamed through LDS in 16-KiB "phases".
+#pragma once
+#include <cstdint>
+
+#include "fsnerf_hip.h"
+
+#if defined(__HIPCC__)
+#define FSN_HD __host__ __device__ __forceinline__
+#else
+#define FSN_HD inline
+#endif
+
+namespace fsn {
+
+constexpr uint32_t kBlobMagic = 0x4e53460au;  // "\nFSN"
+constexpr int kPhaseBytes = 16384;
+constexpr int kKsPos = 4;  // k-steps (of 16) reserved for the positional encoding: 64 slots
+constexpr int kKsDir = 2;  // k-steps reserved for the direction encoding: 32 slots
+constexpr int kMaxLayers = 16;
+
+FSN_HD int unit_bytes(int prec) { return prec == FSN_PREC_BF16X3 ? 2048 : 1024; }
+FSN_HD int units_per_phase(int prec) { return kPhaseBytes / unit_bytes(prec); }
+
+// One GEMM of the network as the kernel sees it.
+struct LayerGeom {
+  int32_t nt_out;      // 32-row output tiles
+  int32_t ks_act;      // k-steps fed by the previous layer's activations (2 per 32 features)
+  int32_t ks_enc;      // k-steps fed by an encoding (kKsPos / kKsDir) or 0
+  int32_t enc_is_dir;  // which encoding
+  int32_t n_freqs;     // of that encoding
+  int32_t d_act;       // input columns coming from activations (0 for layer 0)
+  int32_t ld;          // row stride of the source weight matrix (= in_features)
+  int32_t unit0;       // first unit of this layer in the stream
+};
+
+struct NetGeom {
+  int32_t n_gemm;  // n_layers + 2 (connection, branch)
+  LayerGeom g[kMaxLayers + 2];
+  int32_t units_hidden;  // units of layers 0..n_layers-1 (density-only pass stops here)
+  int32_t units_total;
+  int32_t nph_density, nph_full;  // phases per pass
+  // aux region (float32 offsets)
+  int32_t aux_bias[kMaxLayers + 2];
+  int32_t aux_wsigma, aux_wrgb, aux_misc, aux_floats;
+  int64_t aux_off, stream_off, total_bytes;  // byte offsets in the blob
+};
+
+// Encoding slot -> feature index of the reference's PositionalEncoder layout
+// (src/core/models.py:28,37-39: [x, sin f0 x, cos f0 x, sin f1 x, ...], blocks d_in=3 wide), or -1.
+// Half h (= lane>>5) of a sample's lane pair owns `slots` slots q = 8*ks + j.  Pair p = 3*band+coord
+// goes to half p&1 at slots (2i, 2i+1) = (sin, cos) with i = p>>1; the identity features x,y sit in
+// half 0's last two slots and z in half 1's second to last.
+FSN_HD int enc_slot_feature(int q, int h, int n_freqs, int slots) {
+  const int P = 3 * n_freqs;
+  const int np = (P - h + 1) / 2;  // pairs owned by this half
+  if (q >= slots - 2) {
+    const int id = q - (slots - 2);
+    if (h == 0) return id;           // x, y
+    return id == 0 ? 2 : -1;          // z, pad
+  }
+  if (q < 2 * np) {
+    const int p = 2 * (q >> 1) + h;
+    const int band = p / 3, coord = p - 3 * band;
+    return 3 + band * 6 + (q & 1) * 3 + coord;
+  }
+  return -1;
+}
+
+// Source column of weight fragment element (k-step ks, lane half h, element j) for a layer;
+// -1 = zero padding.  Activation k-steps use the accumulator-as-operand order
+//   feature = 32 (ks>>1) + 16 (ks&1) + 8 (j>>2) + 4 h + (j&3)
+// (cdna_hip_programming.md section 3, "An accumulator tile as the next MFMA's operand").
+FSN_HD int unit_src_col(const LayerGeom& L, int ks, int h, int j) {
+  if (ks < L.ks_act) return 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
+  const int e = ks - L.ks_act;
+  const int slots = 8 * L.ks_enc;
+  const int f = enc_slot_feature(8 * e + j, h, L.n_freqs, slots);
+  return f < 0 ? -1 : L.d_act + f;
+}
+
+FSN_HD uint16_t bf16_rne(float f) {
+  union { float f; uint32_t u; } v;
+  v.f = f;
+  if ((v.u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((v.u >> 16) | 0x40);  // NaN stays NaN
+  return (uint16_t)((v.u + 0x7fffu + ((v.u >> 16) & 1u)) >> 16);
+}
+FSN_HD float bf16_to_f32(uint16_t b) {
+  union { float f; uint32_t u; } v;
+  v.u = (uint32_t)b << 16;
+  return v.f;
+}
+
+// Fills `G` from the descriptor; returns 0 or an FSN_E_* code (message via set_error on host).
+inline int build_geom(const fsn_mlp_desc& d, int prec, NetGeom& G, const char** why) {
+  *why = "";
+  if (prec != FSN_PREC_BF16X3 && prec != FSN_PREC_BF16) { *why = "unknown precision mode"; return FSN_E_INVALID; }
+  if (d.d_hidden != 256 && d.d_hidden != 128) { *why = "d_hidden must be 128 or 256"; return FSN_E_UNSUPPORTED; }
+  if (d.n_layers < 2 || d.n_layers > kMaxLayers) { *why = "n_layers must be in [2,16]"; return FSN_E_UNSUPPORTED; }
+  if (d.n_freqs_pos < 0 || d.n_freqs_pos > 10) { *why = "n_freqs (position) must be <= 10"; return FSN_E_UNSUPPORTED; }
+  if (d.n_freqs_dir < 0 || d.n_freqs_dir > 4) { *why = "n_freqs (direction) must be <= 4"; return FSN_E_UNSUPPORTED; }
+  if (d.skip_mask >> (d.n_layers - 1)) { *why = "skip index >= n_layers-1 (the reference model cannot run it either)"; return FSN_E_INVALID; }
+  const int D = d.d_hidden, NT = D / 32, L = d.n_layers;
+  const int d_pe = 3 * (1 + 2 * d.n_freqs_pos), d_de = 3 * (1 + 2 * d.n_freqs_dir);
+  int u = 0;
+  for (int l = 0; l < L; ++l) {
+    LayerGeom& g = G.g[l];
+    const bool wide = l > 0 && ((d.skip_mask >> (l - 1)) & 1u);
+    g.nt_out = NT;
+    g.ks_act = l == 0 ? 0 : 2 * NT;
+    g.ks_enc = (l == 0 || wide) ? kKsPos : 0;
+    g.enc_is_dir = 0;
+    g.n_freqs = d.n_freqs_pos;
+    g.d_act = l == 0 ? 0 : D;
+    g.ld = g.d_act + (g.ks_enc ? d_pe : 0);
+    g.unit0 = u;
+    u += g.nt_out * (g.ks_act + g.ks_enc);
+  }
+  G.units_hidden = u;
+  LayerGeom& c = G.g[L];  // connection
+  c = LayerGeom{NT, 2 * NT, 0, 0, 0, D, D, u};
+  u += NT * 2 * NT;
+  LayerGeom& b = G.g[L + 1];  // branch
+  b = LayerGeom{NT / 2, 2 * NT, kKsDir, 1, d.n_freqs_dir, D, D + d_de, u};
+  u += (NT / 2) * (2 * NT + kKsDir);
+  G.n_gemm = L + 2;
+  G.units_total = u;
+  const int upp = units_per_phase(prec);
+  if (G.units_hidden % upp) { *why = "internal: hidden units not phase aligned"; return FSN_E_UNSUPPORTED; }
+  G.nph_density = G.units_hidden / upp;
+  G.nph_full = (G.units_total + upp - 1) / upp;
+  int a = 0;
+  for (int l = 0; l < L + 2; ++l) { G.aux_bias[l] = a; a += D; }
+  G.aux_wsigma = a; a += D;
+  G.aux_wrgb = a; a += 2 * D;  // [3][D/2]
+  G.aux_misc = a; a += 4 + 32;  // b_sigma, b_rgb[3], freqs_pos[16], freqs_dir[16]
+  G.aux_floats = (a + 63) / 64 * 64;
+  G.aux_off = 256;
+  G.stream_off = (G.aux_off + (int64_t)G.aux_floats * 4 + 4095) / 4096 * 4096;
+  G.total_bytes = G.stream_off + (int64_t)G.nph_full * kPhaseBytes;
+  return FSN_OK;
+}
+
+}  // namespace fsn

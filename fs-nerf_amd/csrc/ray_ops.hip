@@ -1,0 +1,279 @@
+// ray_ops.hip — the HBM-bound pieces of the path as standalone kernels + their C-ABI:
+// get_rays, to_ndc, posenc_fwd, stratified_edges, edges_to_packed, sample_pdf_merge,
+// composite (dense and packed).  All are streaming kernels: coalesced row-major access,
+// one thread per output element or one wavefront per ray.
+#include "common.hpp"
+#include "ray_dev.hpp"
+
+namespace fsn {
+
+// ---------------------------------------------------------------- get_rays
+// reference: src/utils/utilities.py:36-82.  One thread per pixel.
+struct Pose34 { float m[12]; };
+
+__global__ void k_get_rays(Pose34 P, int W, float half_w, float half_h, float focal, int row0,
+                           int64_t npix, float* __restrict__ ro, float* __restrict__ rd) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npix) return;
+  const int h = row0 + (int)(p / W);
+  const int w = (int)(p % W);
+  float dx = ((float)w - half_w) / focal;
+  float dy = -((float)h - half_h) / focal;
+  float dz = -1.0f;
+  const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+  dx = dx / nrm;
+  dy = dy / nrm;
+  dz = dz / nrm;
+  float* d = rd + 3 * p;
+  float* o = ro + 3 * p;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    d[k] = (dx * P.m[4 * k + 0] + dy * P.m[4 * k + 1]) + dz * P.m[4 * k + 2];
+    o[k] = P.m[4 * k + 3];
+  }
+}
+
+// ---------------------------------------------------------------- to_ndc
+// reference: src/utils/utilities.py:84-120
+__global__ void k_to_ndc(const float* __restrict__ ro, const float* __restrict__ rd, int64_t n,
+                         float sx, float sy, float near, float two_near, float* __restrict__ no,
+                         float* __restrict__ nd) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float dx = rd[3 * i], dy = rd[3 * i + 1], dz = rd[3 * i + 2];
+  float ox = ro[3 * i], oy = ro[3 * i + 1], oz = ro[3 * i + 2];
+  const float t = -(near + oz) / dz;
+  ox = ox + t * dx;
+  oy = oy + t * dy;
+  oz = oz + t * dz;
+  no[3 * i + 0] = sx * ox / oz;
+  no[3 * i + 1] = sy * oy / oz;
+  no[3 * i + 2] = 1.0f + two_near / oz;
+  nd[3 * i + 0] = sx * (dx / dz - ox / oz);
+  nd[3 * i + 1] = sy * (dy / dz - oy / oz);
+  nd[3 * i + 2] = -two_near / oz;
+}
+
+// ---------------------------------------------------------------- posenc
+// reference: src/core/models.py:43-50.  One thread per output element (coalesced writes).
+struct Freqs { float f[16]; };
+
+__global__ void k_posenc(const float* __restrict__ x, int64_t n, int d_in, int n_freqs, Freqs fr,
+                         const float* __restrict__ mask, float* __restrict__ out) {
+  const int d_out = d_in * (1 + 2 * n_freqs);
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * d_out) return;
+  const int64_t p = e / d_out;
+  const int f = (int)(e - p * d_out);
+  float v;
+  if (f < d_in) {
+    v = x[p * d_in + f];
+  } else {
+    const int q = f - d_in;
+    const int band = q / (2 * d_in);
+    const int r = q - band * 2 * d_in;
+    const int c = (r < d_in) ? r : r - d_in;
+    const float a = x[p * d_in + c] * fr.f[band];
+    v = (r < d_in) ? sinf(a) : cosf(a);
+  }
+  if (mask) v = v * mask[f];
+  out[e] = v;
+}
+
+// ---------------------------------------------------------------- sampler
+__global__ void k_stratified_edges(float near, float step, int S, int64_t R, const float* __restrict__ u,
+                                   int u_mode, float* __restrict__ edges) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= R * (S + 1)) return;
+  const int64_t r = e / (S + 1);
+  const int i = (int)(e - r * (S + 1));
+  const float* ur = (u_mode == 1) ? u + r : ((u_mode == 2) ? u + r * (S + 1) : nullptr);
+  edges[e] = stratified_edge(near, step, S, i, u_mode, ur);
+}
+
+__global__ void k_edges_to_packed(const float* __restrict__ edges, int64_t R, int S,
+                                  int64_t* __restrict__ ri, float* __restrict__ t0, float* __restrict__ t1) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= R * S) return;
+  const int64_t r = e / S;
+  const int i = (int)(e - r * S);
+  ri[e] = r;
+  t0[e] = edges[r * (S + 1) + i];
+  t1[e] = edges[r * (S + 1) + i + 1];
+}
+
+// one wave per ray, 4 rays per 256-thread block; dynamic LDS = 4 * (2*S+2+n_imp) floats
+__global__ void k_sample_pdf_merge(const float* __restrict__ edges, const float* __restrict__ w, int64_t R,
+                                   int S, int n_imp, const float* __restrict__ u, float* __restrict__ out) {
+  extern __shared__ float smem[];
+  const int wave = threadIdx.x >> 6;
+  const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+  if (r >= R) return;
+  const int M = S + 1 + n_imp;
+  float* cdf_s = smem + (size_t)wave * (S + 1 + M);
+  float* vals_s = cdf_s + (S + 1);
+  sample_pdf_merge_ray(edges + r * (S + 1), w + r * S, S, n_imp, u ? u + r * n_imp : nullptr, cdf_s, vals_s,
+                       out + r * M);
+}
+
+// ---------------------------------------------------------------- compositing
+struct Bkgd { int has; float c[3]; };
+
+__global__ void k_composite_dense(const float* __restrict__ sig, const float* __restrict__ rgb,
+                                  const float* __restrict__ t0, const float* __restrict__ t1, int64_t R, int S,
+                                  Bkgd bk, float* __restrict__ colors, float* __restrict__ opacity,
+                                  float* __restrict__ depth, float* __restrict__ weights,
+                                  float* __restrict__ alphas, float* __restrict__ trans) {
+  const int wave = threadIdx.x >> 6;
+  const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+  if (r >= R) return;
+  const int64_t b = r * S;
+  CompositeOut o{colors + 3 * r, opacity + r, depth + r, weights ? weights + b : nullptr,
+                 alphas ? alphas + b : nullptr, trans ? trans + b : nullptr};
+  composite_ray(sig + b, rgb + 3 * b, t0 + b, t1 + b, S, bk.has != 0, bk.c[0], bk.c[1], bk.c[2], o);
+}
+
+// packed form: the ray's sample range is found by two binary searches in the sorted
+// ray_indices, then the same per-wave routine runs on that slice.
+__device__ __forceinline__ int64_t lower_bound_i64(const int64_t* __restrict__ a, int64_t n, int64_t key) {
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (a[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ void k_composite_packed(const float* __restrict__ sig, const float* __restrict__ rgb,
+                                   const float* __restrict__ t0, const float* __restrict__ t1,
+                                   const int64_t* __restrict__ ri, int64_t N, int64_t R, Bkgd bk,
+                                   float* __restrict__ colors, float* __restrict__ opacity,
+                                   float* __restrict__ depth, float* __restrict__ weights,
+                                   float* __restrict__ alphas, float* __restrict__ trans) {
+  const int wave = threadIdx.x >> 6;
+  const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+  if (r >= R) return;
+  const int64_t b = lower_bound_i64(ri, N, r);
+  const int64_t e = lower_bound_i64(ri, N, r + 1);
+  CompositeOut o{colors + 3 * r, opacity + r, depth + r, weights ? weights + b : nullptr,
+                 alphas ? alphas + b : nullptr, trans ? trans + b : nullptr};
+  composite_ray(sig + b, rgb + 3 * b, t0 + b, t1 + b, (int)(e - b), bk.has != 0, bk.c[0], bk.c[1], bk.c[2], o);
+}
+
+static inline unsigned nblocks(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace fsn
+
+using namespace fsn;
+
+extern "C" int fsn_get_rays(const float* pose_host, int H, int W, double focal, int row0, int nrows,
+                            float* rays_o, float* rays_d, fsn_stream_t stream) {
+  FSN_REQUIRE(pose_host && rays_o && rays_d, FSN_E_INVALID, "fsn_get_rays: null pointer");
+  FSN_REQUIRE(H > 0 && W > 0 && focal > 0 && row0 >= 0 && nrows >= 0 && row0 + nrows <= H, FSN_E_INVALID,
+              "fsn_get_rays: bad geometry H=%d W=%d focal=%g rows [%d,+%d)", H, W, focal, row0, nrows);
+  const int64_t npix = (int64_t)nrows * W;
+  if (npix == 0) return FSN_OK;
+  Pose34 P;
+  for (int i = 0; i < 12; ++i) P.m[i] = pose_host[i];
+  // W*0.5 and H*0.5 are formed in double by Python and then rounded to float32 (utilities.py:67)
+  k_get_rays<<<nblocks(npix, 256), 256, 0, as_stream(stream)>>>(P, W, (float)(W * 0.5), (float)(H * 0.5),
+                                                               (float)focal, row0, npix, rays_o, rays_d);
+  FSN_LAUNCH_CHECK("k_get_rays");
+  return FSN_OK;
+}
+
+extern "C" int fsn_to_ndc(const float* rays_o, const float* rays_d, int64_t n, int H, int W, double focal,
+                          double near, float* ndc_o, float* ndc_d, fsn_stream_t stream) {
+  FSN_REQUIRE(n >= 0 && H > 0 && W > 0 && focal > 0, FSN_E_INVALID, "fsn_to_ndc: bad arguments");
+  if (n == 0) return FSN_OK;
+  FSN_REQUIRE(rays_o && rays_d && ndc_o && ndc_d, FSN_E_INVALID, "fsn_to_ndc: null pointer");
+  const float sx = (float)(-1.0 / (W / (2.0 * focal)));
+  const float sy = (float)(-1.0 / (H / (2.0 * focal)));
+  k_to_ndc<<<nblocks(n, 256), 256, 0, as_stream(stream)>>>(rays_o, rays_d, n, sx, sy, (float)near,
+                                                          (float)(2.0 * near), ndc_o, ndc_d);
+  FSN_LAUNCH_CHECK("k_to_ndc");
+  return FSN_OK;
+}
+
+extern "C" int fsn_posenc_fwd(const float* x, int64_t n, int d_in, int n_freqs, const float* freqs_host,
+                              const float* mask, float* out, fsn_stream_t stream) {
+  FSN_REQUIRE(n >= 0 && d_in > 0 && n_freqs >= 0, FSN_E_INVALID, "fsn_posenc_fwd: bad sizes");
+  FSN_REQUIRE(n_freqs <= 16, FSN_E_UNSUPPORTED, "fsn_posenc_fwd: n_freqs=%d > 16", n_freqs);
+  if (n == 0) return FSN_OK;
+  FSN_REQUIRE(x && out && (freqs_host || n_freqs == 0), FSN_E_INVALID, "fsn_posenc_fwd: null pointer");
+  Freqs fr{};
+  for (int i = 0; i < n_freqs; ++i) fr.f[i] = freqs_host[i];
+  const int64_t tot = n * d_in * (1 + 2 * n_freqs);
+  k_posenc<<<nblocks(tot, 256), 256, 0, as_stream(stream)>>>(x, n, d_in, n_freqs, fr, mask, out);
+  FSN_LAUNCH_CHECK("k_posenc");
+  return FSN_OK;
+}
+
+extern "C" int fsn_stratified_edges(float near, float far, int S, int64_t R, const float* u, int u_mode,
+                                    float* edges, fsn_stream_t stream) {
+  FSN_REQUIRE(S > 0 && R >= 0 && u_mode >= 0 && u_mode <= 2, FSN_E_INVALID, "fsn_stratified_edges: bad arguments");
+  if (R == 0) return FSN_OK;
+  FSN_REQUIRE(edges && (u_mode == 0 || u), FSN_E_INVALID, "fsn_stratified_edges: null pointer");
+  const float step = (float)(((double)far - (double)near) / S);
+  k_stratified_edges<<<nblocks(R * (S + 1), 256), 256, 0, as_stream(stream)>>>(near, step, S, R, u, u_mode, edges);
+  FSN_LAUNCH_CHECK("k_stratified_edges");
+  return FSN_OK;
+}
+
+extern "C" int fsn_edges_to_packed(const float* edges, int64_t R, int S, int64_t* ray_indices, float* t_starts,
+                                   float* t_ends, fsn_stream_t stream) {
+  FSN_REQUIRE(S > 0 && R >= 0, FSN_E_INVALID, "fsn_edges_to_packed: bad sizes");
+  if (R == 0) return FSN_OK;
+  FSN_REQUIRE(edges && ray_indices && t_starts && t_ends, FSN_E_INVALID, "fsn_edges_to_packed: null pointer");
+  k_edges_to_packed<<<nblocks(R * S, 256), 256, 0, as_stream(stream)>>>(edges, R, S, ray_indices, t_starts, t_ends);
+  FSN_LAUNCH_CHECK("k_edges_to_packed");
+  return FSN_OK;
+}
+
+extern "C" int fsn_sample_pdf_merge(const float* edges, const float* weights, int64_t R, int S, int n_imp,
+                                    const float* u, float* edges_out, fsn_stream_t stream) {
+  FSN_REQUIRE(S > 0 && R >= 0 && n_imp >= 0, FSN_E_INVALID, "fsn_sample_pdf_merge: bad sizes");
+  if (R == 0) return FSN_OK;
+  FSN_REQUIRE(edges && weights && edges_out, FSN_E_INVALID, "fsn_sample_pdf_merge: null pointer");
+  const size_t lds = 4 * (size_t)(2 * S + 2 + n_imp) * sizeof(float);
+  FSN_REQUIRE(lds <= 64 * 1024, FSN_E_UNSUPPORTED, "fsn_sample_pdf_merge: S=%d n_imp=%d too large", S, n_imp);
+  k_sample_pdf_merge<<<nblocks(R, 4), 256, lds, as_stream(stream)>>>(edges, weights, R, S, n_imp, u, edges_out);
+  FSN_LAUNCH_CHECK("k_sample_pdf_merge");
+  return FSN_OK;
+}
+
+static Bkgd make_bkgd(const float* b) {
+  Bkgd k{};
+  if (b) { k.has = 1; k.c[0] = b[0]; k.c[1] = b[1]; k.c[2] = b[2]; }
+  return k;
+}
+
+extern "C" int fsn_composite_fwd(const float* sigmas, const float* rgbs, const float* t_starts, const float* t_ends,
+                                 int64_t R, int S, const float* bkgd_host, float* colors, float* opacity,
+                                 float* depth, float* weights, float* alphas, float* trans, fsn_stream_t stream) {
+  FSN_REQUIRE(R >= 0 && S >= 0, FSN_E_INVALID, "fsn_composite_fwd: bad sizes");
+  if (R == 0) return FSN_OK;
+  FSN_REQUIRE(colors && opacity && depth, FSN_E_INVALID, "fsn_composite_fwd: null output");
+  FSN_REQUIRE(S == 0 || (sigmas && rgbs && t_starts && t_ends), FSN_E_INVALID, "fsn_composite_fwd: null input");
+  k_composite_dense<<<nblocks(R, 4), 256, 0, as_stream(stream)>>>(sigmas, rgbs, t_starts, t_ends, R, S,
+                                                                 make_bkgd(bkgd_host), colors, opacity, depth,
+                                                                 weights, alphas, trans);
+  FSN_LAUNCH_CHECK("k_composite_dense");
+  return FSN_OK;
+}
+
+extern "C" int fsn_composite_packed_fwd(const float* sigmas, const float* rgbs, const float* t_starts,
+                                        const float* t_ends, const int64_t* ray_indices, int64_t N, int64_t R,
+                                        const float* bkgd_host, float* colors, float* opacity, float* depth,
+                                        float* weights, float* alphas, float* trans, fsn_stream_t stream) {
+  FSN_REQUIRE(R >= 0 && N >= 0, FSN_E_INVALID, "fsn_composite_packed_fwd: bad sizes");
+  if (R == 0) return FSN_OK;
+  FSN_REQUIRE(colors && opacity && depth, FSN_E_INVALID, "fsn_composite_packed_fwd: null output");
+  FSN_REQUIRE(N == 0 || (sigmas && rgbs && t_starts && t_ends && ray_indices), FSN_E_INVALID,
+              "fsn_composite_packed_fwd: null input");
+  k_composite_packed<<<nblocks(R, 4), 256, 0, as_stream(stream)>>>(sigmas, rgbs, t_starts, t_ends, ray_indices, N, R,
+                                                                  make_bkgd(bkgd_host), colors, opacity, depth,
+                                                                  weights, alphas, trans);
+  FSN_LAUNCH_CHECK("k_composite_packed");
+  return FSN_OK;
+}

@@ -1,0 +1,206 @@
+// render.hip — the whole hot path of render_rays (src/render/rendering.py:25-107) in ONE launch:
+//   stratified interval edges -> [density pass of the coarse net -> per-ray weights (wave scan)
+//   -> inverse-CDF resampling + sorted union] -> full pass of the fine net -> alpha compositing.
+// A workgroup (4 waves) owns a group of G rays; sample positions, densities, colours, weights
+// and the resampled edges live in LDS; the two MLP passes run on the matrix cores
+// (mlp_dev.hpp) with the weight stream continuing seamlessly from pass to pass and from ray
+// group to ray group; per-ray scans/reductions are done by one wavefront per ray (ray_dev.hpp).
+// HBM traffic is the rays in and the requested outputs out.
+#include "common.hpp"
+#include "mlp_dev.hpp"
+#include "ray_dev.hpp"
+
+namespace fsn {
+
+constexpr int kMaxGroupSamples = 512;  // G * (S + n_imp) <= this
+constexpr int kMaxRaySamples = 512;    // S + n_imp <= this
+constexpr int kMaxG = 8;
+
+struct RenderKArgs {
+  NetParams netC, netF;
+  fsn_render_args a;
+  int32_t G, nsubC, nsubF;
+  float step;
+};
+
+struct RenderLds {
+  float rays[kMaxG * 6];
+  float edgesC[kMaxGroupSamples + kMaxG];
+  float sigC[kMaxGroupSamples];
+  float wC[kMaxGroupSamples];
+  float edgesF[kMaxGroupSamples + kMaxG];
+  float sigF[kMaxGroupSamples];
+  float rgbF[3 * kMaxGroupSamples];
+  float cdf[4][kMaxRaySamples + 1];
+  float vals[4][kMaxRaySamples + 1];
+};
+
+constexpr int kNetLdsBytes = (kAuxCapFloats + 96) * 4;
+constexpr int kRenderLdsBytes = kRingBytes + 2 * kNetLdsBytes + (int)sizeof(RenderLds);
+static_assert(kRenderLdsBytes <= 160 * 1024, "LDS budget");
+
+template <int NT, int PREC>
+__global__ __launch_bounds__(256) void k_render_fused(RenderKArgs k) {
+  __shared__ __attribute__((aligned(1024))) char smem[kRenderLdsBytes];
+  float* auxC = reinterpret_cast<float*>(smem + kRingBytes);
+  float* auxF = reinterpret_cast<float*>(smem + kRingBytes + kNetLdsBytes);
+  RenderLds& S_ = *reinterpret_cast<RenderLds*>(smem + kRingBytes + 2 * kNetLdsBytes);
+  const fsn_render_args& a = k.a;
+  const int S = a.S, NI = a.n_imp, So = S + NI, G = k.G;
+  const bool hier = NI > 0;
+  NetDev netC, netF;
+  load_net(k.netF, a.pos_mask, a.dir_mask, auxF, netF);
+  if (hier) load_net(k.netC, a.pos_mask, a.dir_mask, auxC, netC);
+  else netC = netF;
+  __syncthreads();
+  WStream st;
+  st.init(smem, k.netC.blob + k.netC.stream_off, hier ? (uint32_t)k.netC.nph_density : 0u, (uint32_t)k.nsubC,
+          k.netF.blob + k.netF.stream_off, (uint32_t)k.netF.nph_full, (uint32_t)k.nsubF);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t R = a.R;
+  const int64_t ngroups = (R + G - 1) / G;
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t r0 = grp * G;
+    // ---- rays and coarse interval edges into LDS
+    if (tid < G * 6) {
+      const int g = tid / 6, c = tid - 6 * g;
+      const int64_t ray = min(r0 + g, R - 1);
+      S_.rays[tid] = c < 3 ? a.rays_o[3 * ray + c] : a.rays_d[3 * ray + c - 3];
+    }
+    for (int e = tid; e < G * (S + 1); e += 256) {
+      const int g = e / (S + 1), i = e - g * (S + 1);
+      const int64_t ray = min(r0 + g, R - 1);
+      const float* ur = a.u_mode == 1 ? a.u + ray : (a.u_mode == 2 ? a.u + ray * (S + 1) : nullptr);
+      S_.edgesC[e] = stratified_edge(a.near, k.step, S, i, a.u_mode, ur);
+    }
+    lds_barrier();
+    if (hier) {
+      // ---- density pass of the coarse net (sigma_fn, rendering.py:58-64)
+      for (int sub = 0; sub < k.nsubC; ++sub) {
+        const int idx = sub * 128 + wave * 32 + (lane & 31);
+        const int idc = min(idx, G * S - 1);
+        const int g = idc / S, i = idc - g * S;
+        const float t0 = S_.edgesC[g * (S + 1) + i], t1 = S_.edgesC[g * (S + 1) + i + 1];
+        const float* ry = S_.rays + 6 * g;
+        const float tm = t0 + t1;
+        const float px = ry[0] + ry[3] * tm / 2.0f, py = ry[1] + ry[4] * tm / 2.0f, pz = ry[2] + ry[5] * tm / 2.0f;
+        float sigma, rgb[3];
+        mlp_tile<NT, PREC, false>(st, netC, px, py, pz, 0.f, 0.f, 0.f, sigma, rgb);
+        if (lane < 32 && idx < G * S) S_.sigC[idx] = sigma;
+      }
+      lds_barrier();
+      // ---- per-ray weights, inverse-CDF resampling, sorted union (one wave per ray)
+      for (int g = wave; g < G; g += 4) {
+        const int64_t ray = min(r0 + g, R - 1);
+        float* wc = S_.wC + g * S;
+        weights_ray(S_.sigC + g * S, S_.edgesC + g * (S + 1), S, wc);
+        __builtin_amdgcn_wave_barrier();
+        if (a.weights_coarse && r0 + g < R)
+          for (int i = lane; i < S; i += 64) a.weights_coarse[ray * S + i] = wc[i];
+        sample_pdf_merge_ray(S_.edgesC + g * (S + 1), wc, S, NI, a.u_fine ? a.u_fine + ray * NI : nullptr,
+                             S_.cdf[wave], S_.vals[wave], S_.edgesF + g * (So + 1));
+      }
+      lds_barrier();
+    }
+    const float* edges = hier ? S_.edgesF : S_.edgesC;
+    // ---- full pass of the fine net (rgb_sigma_fn, rendering.py:76-84)
+    for (int sub = 0; sub < k.nsubF; ++sub) {
+      const int idx = sub * 128 + wave * 32 + (lane & 31);
+      const int idc = min(idx, G * So - 1);
+      const int g = idc / So, i = idc - g * So;
+      const float t0 = edges[g * (So + 1) + i], t1 = edges[g * (So + 1) + i + 1];
+      const float* ry = S_.rays + 6 * g;
+      const float tm = t0 + t1;
+      const float px = ry[0] + ry[3] * tm / 2.0f, py = ry[1] + ry[4] * tm / 2.0f, pz = ry[2] + ry[5] * tm / 2.0f;
+      float sigma, rgb[3];
+      mlp_tile<NT, PREC, true>(st, netF, px, py, pz, ry[3], ry[4], ry[5], sigma, rgb);
+      if (lane < 32 && idx < G * So) {
+        S_.sigF[idx] = sigma;
+        S_.rgbF[3 * idx + 0] = rgb[0];
+        S_.rgbF[3 * idx + 1] = rgb[1];
+        S_.rgbF[3 * idx + 2] = rgb[2];
+      }
+    }
+    lds_barrier();
+    // ---- volume integration (nerfacc rendering arithmetic, rendering.py:89-96), one wave per ray
+    for (int g = wave; g < G; g += 4) {
+      if (r0 + g >= R) continue;
+      const int64_t ray = r0 + g;
+      const float* eg = edges + g * (So + 1);
+      CompositeOut o{a.colors + 3 * ray, a.opacity + ray, a.depth + ray,
+                     a.weights ? a.weights + ray * So : nullptr, a.alphas ? a.alphas + ray * So : nullptr,
+                     a.trans ? a.trans + ray * So : nullptr};
+      composite_ray(S_.sigF + g * So, S_.rgbF + 3 * g * So, eg, eg + 1, So, true, a.bkgd[0], a.bkgd[1], a.bkgd[2], o);
+      if (a.sigmas)
+        for (int i = lane; i < So; i += 64) a.sigmas[ray * So + i] = S_.sigF[g * So + i];
+      if (a.rgbs)
+        for (int i = lane; i < 3 * So; i += 64) a.rgbs[ray * So * 3 + i] = S_.rgbF[3 * g * So + i];
+      if (a.edges_out)
+        for (int i = lane; i <= So; i += 64) a.edges_out[ray * (So + 1) + i] = eg[i];
+    }
+    lds_barrier();
+  }
+  st.drain();
+}
+
+template <int NT, int PREC>
+static int launch_render(const RenderKArgs& k, int cus, hipStream_t s) {
+  const int64_t ngroups = (k.a.R + k.G - 1) / k.G;
+  const unsigned grid = (unsigned)(ngroups < cus ? ngroups : cus);
+  k_render_fused<NT, PREC><<<grid, 256, 0, s>>>(k);
+  FSN_LAUNCH_CHECK("k_render_fused");
+  return FSN_OK;
+}
+
+static NetParams net_params(const fsn_mlp_desc& d, const NetGeom& G, const void* blob) {
+  NetParams p;
+  p.blob = static_cast<const char*>(blob);
+  p.aux_off = (int32_t)G.aux_off; p.aux_floats = G.aux_floats; p.stream_off = (int32_t)G.stream_off;
+  p.nph_density = G.nph_density; p.nph_full = G.nph_full;
+  p.n_layers = d.n_layers; p.skip_mask = d.skip_mask;
+  p.n_freqs_pos = d.n_freqs_pos; p.n_freqs_dir = d.n_freqs_dir;
+  return p;
+}
+
+}  // namespace fsn
+
+using namespace fsn;
+
+extern "C" int fsn_render_rays_fused(const fsn_mlp_desc* desc, int prec, const void* blob_coarse,
+                                     const void* blob_fine, const fsn_render_args* args, fsn_stream_t stream) {
+  FSN_REQUIRE(desc && args, FSN_E_INVALID, "fsn_render_rays_fused: null pointer");
+  const fsn_render_args& a = *args;
+  FSN_REQUIRE(a.R >= 0 && a.S > 0 && a.n_imp >= 0 && a.u_mode >= 0 && a.u_mode <= 2, FSN_E_INVALID,
+              "fsn_render_rays_fused: bad sizes R=%lld S=%d n_imp=%d u_mode=%d", (long long)a.R, a.S, a.n_imp, a.u_mode);
+  NetGeom G;
+  const char* why;
+  const int rc = build_geom(*desc, prec, G, &why);
+  FSN_REQUIRE(rc == FSN_OK, rc, "fsn_render_rays_fused: %s", why);
+  if (a.R == 0) return FSN_OK;
+  FSN_REQUIRE(blob_fine && a.rays_o && a.rays_d && a.colors && a.opacity && a.depth, FSN_E_INVALID,
+              "fsn_render_rays_fused: null pointer");
+  FSN_REQUIRE(a.n_imp == 0 || blob_coarse, FSN_E_INVALID, "fsn_render_rays_fused: hierarchical sampling needs blob_coarse");
+  FSN_REQUIRE(a.u_mode == 0 || a.u, FSN_E_INVALID, "fsn_render_rays_fused: u_mode %d needs u", a.u_mode);
+  const int So = a.S + a.n_imp;
+  FSN_REQUIRE(So <= kMaxRaySamples, FSN_E_UNSUPPORTED, "fsn_render_rays_fused: S+n_imp=%d > %d", So, kMaxRaySamples);
+  FSN_REQUIRE(G.aux_floats <= kAuxCapFloats, FSN_E_UNSUPPORTED, "fsn_render_rays_fused: network too deep for LDS");
+  RenderKArgs k;
+  k.netF = net_params(*desc, G, blob_fine);
+  k.netC = net_params(*desc, G, a.n_imp > 0 ? blob_coarse : blob_fine);
+  k.a = a;
+  int g = 128 / a.S;
+  if (g < 1) g = 1;
+  if (g > kMaxGroupSamples / So) g = kMaxGroupSamples / So;
+  if (g > kMaxG) g = kMaxG;
+  if (g < 1) g = 1;
+  k.G = g;
+  k.nsubC = (g * a.S + 127) / 128;
+  k.nsubF = (g * So + 127) / 128;
+  k.step = (float)(((double)a.far - (double)a.near) / a.S);
+  const int cus = fsn_device_cus();
+  if (cus <= 0) return FSN_E_HIP;
+  hipStream_t s = as_stream(stream);
+  if (desc->d_hidden == 256)
+    return prec == FSN_PREC_BF16X3 ? launch_render<8, FSN_PREC_BF16X3>(k, cus, s) : launch_render<8, FSN_PREC_BF16>(k, cus, s);
+  return prec == FSN_PREC_BF16X3 ? launch_render<4, FSN_PREC_BF16X3>(k, cus, s) : launch_render<4, FSN_PREC_BF16>(k, cus, s);
+}

@@ -1,0 +1,280 @@
+"""Tensor-level wrappers over the C-ABI (include/fsnerf_hip.h).  Every function here launches
+HIP kernels on the current torch stream; inputs must live on the GPU (float32, contiguous).
+No function in this module computes anything on the CPU."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib as L
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32(t: Tensor, name: str) -> Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback)")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _bk(bkgd) -> Optional[C.Array]:
+    if bkgd is None:
+        return None
+    vals = [float(v) for v in (bkgd.detach().cpu().tolist() if isinstance(bkgd, Tensor) else bkgd)]
+    return (C.c_float * 3)(*vals)
+
+
+# ------------------------------------------------------------------ rays
+def get_rays(pose: Tensor, H: int, W: int, focal: float, device, row0: int = 0,
+             nrows: Optional[int] = None) -> Tuple[Tensor, Tensor]:
+    nrows = H - row0 if nrows is None else nrows
+    p = pose.detach().to("cpu", torch.float32)[:3, :4].contiguous()
+    pose_host = (C.c_float * 12)(*p.reshape(-1).tolist())
+    o = torch.empty(nrows * W, 3, device=device, dtype=torch.float32)
+    d = torch.empty_like(o)
+    with torch.cuda.device(o.device):
+        L.check(L.lib().fsn_get_rays(pose_host, H, W, float(focal), row0, nrows, _p(o), _p(d), _stream()),
+                "fsn_get_rays")
+    return o, d
+
+
+def to_ndc(rays_o: Tensor, rays_d: Tensor, H: int, W: int, focal: float, near: float) -> Tuple[Tensor, Tensor]:
+    o, d = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d")
+    n = o.numel() // 3
+    no, nd = torch.empty_like(o), torch.empty_like(d)
+    with torch.cuda.device(o.device):
+        L.check(L.lib().fsn_to_ndc(_p(o), _p(d), n, H, W, float(focal), float(near), _p(no), _p(nd), _stream()),
+                "fsn_to_ndc")
+    return no, nd
+
+
+def posenc(x: Tensor, freqs: Sequence[float], mask: Optional[Tensor] = None) -> Tensor:
+    x = _f32(x, "x")
+    d_in = x.shape[-1]
+    n = x.numel() // d_in
+    nf = len(freqs)
+    out = torch.empty(*x.shape[:-1], d_in * (1 + 2 * nf), device=x.device, dtype=torch.float32)
+    fr = (C.c_float * max(nf, 1))(*[float(f) for f in freqs])
+    m = None if mask is None else _f32(mask, "mask")
+    with torch.cuda.device(x.device):
+        L.check(L.lib().fsn_posenc_fwd(_p(x), n, d_in, nf, fr, _p(m), _p(out), _stream()), "fsn_posenc_fwd")
+    return out
+
+
+# ------------------------------------------------------------------ sampling
+def _u_mode(u: Optional[Tensor], R: int, S: int) -> Tuple[int, Optional[Tensor]]:
+    if u is None:
+        return 0, None
+    u = _f32(u, "u")
+    if u.numel() == R:
+        return 1, u
+    if tuple(u.shape) == (R, S + 1):
+        return 2, u
+    raise ValueError(f"jitter u must have {R} or {R}x{S + 1} elements, got {tuple(u.shape)}")
+
+
+def stratified_edges(near: float, far: float, S: int, R: int, u: Optional[Tensor], device) -> Tensor:
+    mode, u = _u_mode(u, R, S)
+    edges = torch.empty(R, S + 1, device=device, dtype=torch.float32)
+    with torch.cuda.device(edges.device):
+        L.check(L.lib().fsn_stratified_edges(float(near), float(far), S, R, _p(u), mode, _p(edges), _stream()),
+                "fsn_stratified_edges")
+    return edges
+
+
+def edges_to_packed(edges: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    edges = _f32(edges, "edges")
+    R, S = edges.shape[0], edges.shape[1] - 1
+    ri = torch.empty(R * S, device=edges.device, dtype=torch.int64)
+    t0 = torch.empty(R * S, device=edges.device, dtype=torch.float32)
+    t1 = torch.empty_like(t0)
+    with torch.cuda.device(edges.device):
+        L.check(L.lib().fsn_edges_to_packed(_p(edges), R, S, _p(ri), _p(t0), _p(t1), _stream()),
+                "fsn_edges_to_packed")
+    return ri, t0, t1
+
+
+def sample_pdf_merge(edges: Tensor, weights: Tensor, n_imp: int, u: Optional[Tensor] = None) -> Tensor:
+    edges, weights = _f32(edges, "edges"), _f32(weights, "weights")
+    R, S = weights.shape
+    assert edges.shape == (R, S + 1)
+    u = None if u is None else _f32(u, "u")
+    out = torch.empty(R, S + 1 + n_imp, device=edges.device, dtype=torch.float32)
+    with torch.cuda.device(edges.device):
+        L.check(L.lib().fsn_sample_pdf_merge(_p(edges), _p(weights), R, S, n_imp, _p(u), _p(out), _stream()),
+                "fsn_sample_pdf_merge")
+    return out
+
+
+# ------------------------------------------------------------------ compositing
+def composite(sigmas: Tensor, rgbs: Tensor, t_starts: Tensor, t_ends: Tensor, bkgd=None, extras: bool = True):
+    """Dense [R,S] volume integration.  Returns colors [R,3], opacity [R,1], depth [R,1], extras."""
+    sig, rgb = _f32(sigmas, "sigmas"), _f32(rgbs, "rgbs")
+    t0, t1 = _f32(t_starts, "t_starts"), _f32(t_ends, "t_ends")
+    R, S = sig.shape
+    dev = sig.device
+    colors = torch.empty(R, 3, device=dev)
+    opacity = torch.empty(R, 1, device=dev)
+    depth = torch.empty(R, 1, device=dev)
+    w = torch.empty(R, S, device=dev) if extras else None
+    a = torch.empty(R, S, device=dev) if extras else None
+    tr = torch.empty(R, S, device=dev) if extras else None
+    with torch.cuda.device(dev):
+        L.check(L.lib().fsn_composite_fwd(_p(sig), _p(rgb), _p(t0), _p(t1), R, S, _bk(bkgd), _p(colors), _p(opacity),
+                                          _p(depth), _p(w), _p(a), _p(tr), _stream()), "fsn_composite_fwd")
+    ex = {"weights": w, "alphas": a, "trans": tr, "sigmas": sig, "rgbs": rgb} if extras else {}
+    return colors, opacity, depth, ex
+
+
+def composite_packed(sigmas: Tensor, rgbs: Tensor, t_starts: Tensor, t_ends: Tensor, ray_indices: Tensor,
+                     n_rays: int, bkgd=None):
+    sig, rgb = _f32(sigmas, "sigmas"), _f32(rgbs, "rgbs")
+    t0, t1 = _f32(t_starts, "t_starts"), _f32(t_ends, "t_ends")
+    ri = ray_indices.contiguous()
+    if ri.dtype != torch.int64:
+        ri = ri.long()
+    N = sig.numel()
+    dev = t0.device
+    colors = torch.empty(n_rays, 3, device=dev)
+    opacity = torch.empty(n_rays, 1, device=dev)
+    depth = torch.empty(n_rays, 1, device=dev)
+    w, a, tr = (torch.empty(N, device=dev) for _ in range(3))
+    with torch.cuda.device(dev):
+        L.check(L.lib().fsn_composite_packed_fwd(_p(sig), _p(rgb), _p(t0), _p(t1), _p(ri), N, n_rays, _bk(bkgd),
+                                                 _p(colors), _p(opacity), _p(depth), _p(w), _p(a), _p(tr), _stream()),
+                "fsn_composite_packed_fwd")
+    return colors, opacity, depth, {"weights": w, "alphas": a, "trans": tr, "sigmas": sig, "rgbs": rgb}
+
+
+# ------------------------------------------------------------------ MLP
+SD_ORDER_TAIL = ("sigma", "connection", "branch", "rgb")
+
+
+def make_desc(n_layers: int, d_hidden: int, skip: Sequence[int], freqs_pos: Sequence[float],
+              freqs_dir: Sequence[float]) -> L.MlpDesc:
+    d = L.MlpDesc()
+    d.n_layers, d.d_hidden = n_layers, d_hidden
+    mask = 0
+    for i in skip:
+        if 0 <= i < n_layers - 1:
+            mask |= 1 << i
+        elif i == n_layers - 1:
+            raise ValueError(f"skip index {i} == n_layers-1: the reference model cannot run this either "
+                             "(sigma expects d_hidden inputs, src/core/models.py:107,123)")
+    d.skip_mask = mask
+    d.n_freqs_pos, d.n_freqs_dir = len(freqs_pos), len(freqs_dir)
+    if len(freqs_pos) > 16 or len(freqs_dir) > 16:
+        raise ValueError("too many frequency bands")
+    for i, f in enumerate(freqs_pos):
+        d.freqs_pos[i] = float(f)
+    for i, f in enumerate(freqs_dir):
+        d.freqs_dir[i] = float(f)
+    return d
+
+
+def sd_tensor_lists(sd: Dict[str, Tensor], n_layers: int) -> Tuple[List[Tensor], List[Tensor]]:
+    names = [f"layers.{i}" for i in range(n_layers)] + list(SD_ORDER_TAIL)
+    return [sd[n + ".weight"] for n in names], [sd[n + ".bias"] for n in names]
+
+
+class PackedMLP:
+    """A reference-format state_dict packed for the MFMA kernels (device blob + descriptor)."""
+
+    def __init__(self, desc: L.MlpDesc, prec: int, device):
+        self.desc, self.prec = desc, prec
+        nbytes = L.lib().fsn_mlp_blob_bytes(C.byref(desc), prec)
+        if nbytes < 0:
+            L.check(int(nbytes), "fsn_mlp_blob_bytes")
+        self.blob = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+    def pack(self, weights: Sequence[Tensor], biases: Sequence[Tensor]) -> "PackedMLP":
+        n = self.desc.n_layers + 4
+        assert len(weights) == n and len(biases) == n
+        ws = [_f32(w.detach(), "weight") for w in weights]
+        bs = [_f32(b.detach(), "bias") for b in biases]
+        Wp = (C.c_void_p * n)(*[w.data_ptr() for w in ws])
+        Bp = (C.c_void_p * n)(*[b.data_ptr() for b in bs])
+        with torch.cuda.device(self.blob.device):
+            L.check(L.lib().fsn_mlp_pack(C.byref(self.desc), self.prec, Wp, Bp, _p(self.blob), _stream()),
+                    "fsn_mlp_pack")
+        self._keep = (ws, bs)  # alive until the stream work is queued behind later launches
+        return self
+
+
+def mlp_fwd(pm: PackedMLP, x: Tensor, dirs: Optional[Tensor] = None, pos_mask: Optional[Tensor] = None,
+            dir_mask: Optional[Tensor] = None) -> Tensor:
+    x = _f32(x, "x")
+    lead = x.shape[:-1]
+    n = x.numel() // 3
+    d = None if dirs is None else _f32(dirs, "dirs")
+    pmk = None if pos_mask is None else _f32(pos_mask, "pos_mask")
+    dmk = None if dir_mask is None else _f32(dir_mask, "dir_mask")
+    out = torch.empty(*lead, 4 if d is not None else 1, device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        L.check(L.lib().fsn_mlp_fwd(C.byref(pm.desc), pm.prec, _p(pm.blob), _p(x), _p(d), _p(pmk), _p(dmk), n,
+                                    _p(out), _stream()), "fsn_mlp_fwd")
+    return out
+
+
+def render_fused(pm_coarse: Optional[PackedMLP], pm_fine: PackedMLP, rays_o: Tensor, rays_d: Tensor, *, near: float,
+                 far: float, n_samples: int, n_importance: int = 0, u: Optional[Tensor] = None,
+                 u_fine: Optional[Tensor] = None, bkgd=(0.0, 0.0, 0.0), pos_mask: Optional[Tensor] = None,
+                 dir_mask: Optional[Tensor] = None, want_extras: bool = True):
+    """One launch for the whole path (fsn_render_rays_fused).  Returns colors [R,3], opacity [R,1],
+    depth [R,1], extras {weights, alphas, trans, sigmas [R,S'], rgbs [R,S',3], edges [R,S'+1],
+    weights_coarse [R,S] (hierarchical only)}."""
+    o, d = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d")
+    R = o.shape[0]
+    S, NI = n_samples, n_importance
+    So = S + NI
+    dev = o.device
+    mode, u = _u_mode(u, R, S)
+    a = L.RenderArgs()
+    a.rays_o, a.rays_d, a.R = o.data_ptr(), d.data_ptr(), R
+    a.near, a.far, a.S, a.n_imp, a.u_mode = float(near), float(far), S, NI, mode
+    keep = [o, d, u]
+    a.u = None if u is None else u.data_ptr()
+    if u_fine is not None:
+        u_fine = _f32(u_fine, "u_fine")
+        assert tuple(u_fine.shape) == (R, NI)
+        a.u_fine = u_fine.data_ptr()
+    for name, m in (("pos_mask", pos_mask), ("dir_mask", dir_mask)):
+        if m is not None:
+            m = _f32(m, name)
+            keep.append(m)
+            setattr(a, name, m.data_ptr())
+    for i in range(3):
+        a.bkgd[i] = float(bkgd[i])
+    colors = torch.empty(R, 3, device=dev)
+    opacity = torch.empty(R, 1, device=dev)
+    depth = torch.empty(R, 1, device=dev)
+    a.colors, a.opacity, a.depth = colors.data_ptr(), opacity.data_ptr(), depth.data_ptr()
+    ex: Dict[str, Tensor] = {}
+    if want_extras:
+        for k, shape in (("weights", (R, So)), ("alphas", (R, So)), ("trans", (R, So)), ("sigmas", (R, So)),
+                         ("rgbs", (R, So, 3))):
+            ex[k] = torch.empty(*shape, device=dev)
+            setattr(a, k, ex[k].data_ptr())
+        ex["edges"] = torch.empty(R, So + 1, device=dev)
+        a.edges_out = ex["edges"].data_ptr()
+        if NI > 0:
+            ex["weights_coarse"] = torch.empty(R, S, device=dev)
+            a.weights_coarse = ex["weights_coarse"].data_ptr()
+    if NI > 0 and pm_coarse is None:
+        pm_coarse = pm_fine
+    with torch.cuda.device(dev):
+        L.check(L.lib().fsn_render_rays_fused(C.byref(pm_fine.desc), pm_fine.prec,
+                                              _p(pm_coarse.blob) if pm_coarse is not None else None,
+                                              _p(pm_fine.blob), C.byref(a), _stream()), "fsn_render_rays_fused")
+    return colors, opacity, depth, ex

@@ -1,0 +1,171 @@
+"""Host-side mirror of the reference's `render/rendering.py` call surface on HIP kernels.
+
+  render_rays(rays_o, rays_d, estimator, model, train, white_bkgd, render_step_size, device)
+      -> ((rgb, opacity, depth, extras), ray_indices, t_vals)           (src/render/rendering.py:25-107)
+  render_frame(hwf, near, far, pose, chunksize, estimator, model, ...)  (src/render/rendering.py:110-177)
+  rendering(t_starts, t_ends, ray_indices, n_rays, rgb_sigma_fn, render_bkgd)
+      the nerfacc.volrend.rendering slot (call site rendering.py:89-96)
+  StratifiedEstimator                     the estimator slot (rendering.py:66-74, run-nerf.py:96-98)
+
+`StratifiedEstimator` is the fixed-count sampler `north_star` asks for (64 coarse + 128
+importance samples) with the duck-typed interface the reference expects from its estimator
+(`sampling`, `update_every_n_steps`, nn.Module modes).  When `model` is this package's NeRF and
+`estimator` a StratifiedEstimator, render_rays runs the single fused launch
+(fsn_render_rays_fused); any other callable model goes through the same HIP sampler /
+compositor kernels with the model evaluated in between, exactly like the reference's closures.
+"""
+from typing import Callable, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from .. import ops
+from ..core.models import NeRF
+from ..utils import utilities as U
+
+
+class StratifiedEstimator(nn.Module):
+    """Fixed-count stratified sampler with optional hierarchical (inverse-CDF) refinement."""
+
+    def __init__(self, near: float, far: float, n_samples: int = 64, n_importance: int = 0,
+                 jitter: str = "ray") -> None:
+        super().__init__()
+        assert jitter in ("ray", "edge")
+        self.near, self.far = float(near), float(far)
+        self.n_samples, self.n_importance, self.jitter = int(n_samples), int(n_importance), jitter
+        self.generator: Optional[torch.Generator] = None  # optional explicit RNG for the jitter
+
+    def bounds(self, near_plane: float = 0.0, far_plane: float = 1e10) -> Tuple[float, float]:
+        return max(self.near, float(near_plane)), min(self.far, float(far_plane))
+
+    def draw_u(self, n_rays: int, device) -> Tensor:
+        shape = (n_rays,) if self.jitter == "ray" else (n_rays, self.n_samples + 1)
+        return torch.rand(*shape, device=device, generator=self.generator)
+
+    @torch.no_grad()
+    def sampling(self, rays_o: Tensor, rays_d: Tensor, sigma_fn: Optional[Callable] = None,
+                 render_step_size: float = 5e-3, stratified: bool = False, near_plane: float = 0.0,
+                 far_plane: float = 1e10, u: Optional[Tensor] = None, u_fine: Optional[Tensor] = None):
+        """-> (ray_indices int64 [N], t_starts [N], t_ends [N]); N = n_rays*(n_samples+n_importance).
+        `render_step_size` is accepted for signature compatibility (the step is (far-near)/n_samples)."""
+        R = rays_o.shape[0]
+        near, far = self.bounds(near_plane, far_plane)
+        if u is None and stratified:
+            u = self.draw_u(R, rays_o.device)
+        edges = ops.stratified_edges(near, far, self.n_samples, R, u, rays_o.device)
+        if self.n_importance > 0:
+            if sigma_fn is None:
+                raise ValueError("hierarchical sampling needs sigma_fn")
+            ri, t0, t1 = ops.edges_to_packed(edges)
+            sig = sigma_fn(t0, t1, ri).reshape(R, self.n_samples)
+            # weights of the density pass = the compositor's weights (colours are irrelevant)
+            _, _, _, ex = ops.composite(sig, torch.zeros(R, self.n_samples, 3, device=sig.device),
+                                        edges[:, :-1].contiguous(), edges[:, 1:].contiguous(), None)
+            if u_fine is None and stratified:
+                u_fine = torch.rand(R, self.n_importance, device=rays_o.device, generator=self.generator)
+            edges = ops.sample_pdf_merge(edges, ex["weights"], self.n_importance, u_fine)
+        return ops.edges_to_packed(edges)
+
+    def update_every_n_steps(self, step: int = 0, occ_eval_fn: Optional[Callable] = None,
+                             occ_thre: float = 1e-2, **_) -> None:
+        """No occupancy state to refresh (run-nerf.py:292-295 calls this every step)."""
+        return None
+
+
+def rendering(t_starts: Tensor, t_ends: Tensor, ray_indices: Tensor, n_rays: int,
+              rgb_sigma_fn: Callable, render_bkgd: Optional[Tensor] = None):
+    """nerfacc.volrend.rendering's contract: -> (colors [n_rays,3], opacities [n_rays,1],
+    depths [n_rays,1], extras).  AssertionError on the same shape violations."""
+    rgbs, sigmas = rgb_sigma_fn(t_starts, t_ends, ray_indices)
+    assert rgbs.shape[-1] == 3, "rgbs must have 3 channels, got {}".format(rgbs.shape)
+    assert sigmas.shape == t_starts.shape, "sigmas must have shape of (N,)! Got {}".format(sigmas.shape)
+    return ops.composite_packed(sigmas, rgbs, t_starts, t_ends, ray_indices, n_rays, render_bkgd)
+
+
+def render_rays(rays_o: Tensor, rays_d: Tensor, estimator, model: nn.Module, train: bool = False,
+                white_bkgd: bool = False, render_step_size: float = 5e-3,
+                device: torch.device = torch.device("cuda"), *, model_fine: Optional[nn.Module] = None,
+                u: Optional[Tensor] = None, u_fine: Optional[Tensor] = None, want_extras: bool = True):
+    """See module docstring.  Keyword-only extras over the reference: `model_fine` (second network
+    of the hierarchical pass; default = `model`, as the reference uses one network for both of
+    its passes), explicit jitter tensors `u` / `u_fine`, `want_extras`."""
+    rays_o = rays_o.to(device)
+    rays_d = rays_d.to(device)
+    bk = float(white_bkgd)
+
+    fused = isinstance(estimator, StratifiedEstimator) and isinstance(model, NeRF) and \
+        (model_fine is None or isinstance(model_fine, NeRF))
+    if fused:
+        R = rays_o.shape[0]
+        fine = model_fine if model_fine is not None else model
+        if u is None and train:
+            u = estimator.draw_u(R, rays_o.device)
+        if u_fine is None and train and estimator.n_importance > 0:
+            u_fine = torch.rand(R, estimator.n_importance, device=rays_o.device, generator=estimator.generator)
+        near, far = estimator.bounds()
+        pm = fine._mask(fine.pos_mask, rays_o.device)
+        dm = fine._mask(fine.dir_mask, rays_o.device)
+        rgb, opacity, depth, ex = ops.render_fused(
+            model.packed() if estimator.n_importance > 0 else None, fine.packed(), rays_o, rays_d,
+            near=near, far=far, n_samples=estimator.n_samples, n_importance=estimator.n_importance,
+            u=u, u_fine=u_fine, bkgd=(bk, bk, bk), pos_mask=pm, dir_mask=dm, want_extras=want_extras)
+        if not want_extras:  # frame rendering: only rgb / depth are consumed (rendering.py:169-171)
+            return (rgb, opacity, depth, ex), None, None
+        edges = ex["edges"]
+        ray_indices, t_starts, t_ends = ops.edges_to_packed(edges)
+        for k in ("weights", "alphas", "trans", "sigmas"):
+            ex[k] = ex[k].reshape(-1)
+        ex["rgbs"] = ex["rgbs"].reshape(-1, 3)
+        output = (rgb, opacity, depth, ex)
+    else:
+        def sigma_fn(t_starts, t_ends, ray_indices):
+            to, td = rays_o[ray_indices], rays_d[ray_indices]
+            x = to + td * (t_starts + t_ends)[:, None] / 2.0
+            return model(x).squeeze(-1)
+
+        ray_indices, t_starts, t_ends = estimator.sampling(
+            rays_o, rays_d, sigma_fn=sigma_fn, render_step_size=render_step_size, stratified=train,
+            near_plane=0.0, far_plane=1e10, **({"u": u, "u_fine": u_fine} if isinstance(estimator, StratifiedEstimator) else {}))
+        fine = model_fine if model_fine is not None else model
+
+        def rgb_sigma_fn(t_starts, t_ends, ray_indices):
+            to, td = rays_o[ray_indices], rays_d[ray_indices]
+            x = to + td * (t_starts + t_ends)[:, None] / 2.0
+            out = fine(x, td)
+            return out[..., :3], out[..., -1]
+
+        render_bkgd = white_bkgd * torch.ones((3,), device=device)
+        try:
+            output = rendering(t_starts, t_ends, ray_indices, n_rays=len(rays_o), rgb_sigma_fn=rgb_sigma_fn,
+                               render_bkgd=render_bkgd)
+        except AssertionError:  # same fallback as the reference (rendering.py:97-103)
+            output = (torch.ones_like(rays_o) * white_bkgd, None,
+                      torch.zeros_like(rays_o[:, 0].unsqueeze(1), dtype=torch.float32), None)
+    t_vals = (t_starts + t_ends) / 2.0
+    return output, ray_indices, t_vals
+
+
+def render_frame(hwf: Tuple[int, int, float], near: float, far: float, pose: Tensor, chunksize: int, estimator,
+                 model: nn.Module, train: bool = False, ndc: bool = False, white_bkgd: bool = False,
+                 render_step_size: float = 5e-3, device: torch.device = torch.device("cuda"), *,
+                 model_fine: Optional[nn.Module] = None) -> Tuple[Tensor, Tensor]:
+    """One image: get_rays -> (ndc) -> chunks -> render_rays -> cat; depth clamped to [near, far]
+    (rendering.py:146-177).  Deliberate difference: the reference passes `white_bkgd` positionally
+    into render_rays' `train` slot (rendering.py:160-168), so its frames are always composited on
+    black; here `train` and `white_bkgd` go to the parameters they name."""
+    H, W, _ = hwf
+    rays_o, rays_d = U.get_rays(pose, hwf, device)
+    rays_o, rays_d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
+    if ndc:
+        rays_o, rays_d = U.to_ndc(rays_o, rays_d, hwf, 1.0)
+    img, depth_map = [], []
+    for co, cd in zip(U.get_chunks(rays_o, chunksize), U.get_chunks(rays_d, chunksize)):
+        out = render_rays(co, cd, estimator, model, train=train, white_bkgd=white_bkgd,
+                          render_step_size=render_step_size, device=device, model_fine=model_fine,
+                          want_extras=False)
+        (rgb, _, depth, _), *_ = out
+        img.append(rgb)
+        depth_map.append(depth)
+    img = torch.cat(img, dim=0)
+    depth = torch.cat(depth_map, dim=0).clamp(near, far)
+    return img.reshape(H, W, 3), depth.reshape(H, W)

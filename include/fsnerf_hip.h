@@ -1,0 +1,165 @@
+/*
+ * fsnerf_hip.h — C-ABI of libfsnerf_hip.so: the NeRF ray-rendering hot path of
+ * a-lemus96/fs-nerf as hand-written HIP kernels for MI355X (gfx950 / CDNA4).
+ *
+ * The reference has no FFI of its own (it is 100 % Python): the path sits
+ * behind Python callables.  Each entry point below therefore names the reference callable
+ * (file:line under /root/reference) whose arithmetic it replaces; the Python host layer in
+ * fs-nerf_amd/ keeps those callables' names and signatures and binds this library with ctypes
+ * (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in `_host`;
+ *   - tensors are dense row-major float32 unless stated; ray_indices is int64
+ *     (reference contract, src/render/rendering.py:66,92);
+ *   - the caller owns all memory; nothing is retained past the call's stream work;
+ *   - all calls are asynchronous on `stream` (a hipStream_t; NULL = default stream);
+ *   - return 0 on success, negative on error (FSN_E_*); the message is available from
+ *     fsn_last_error() (thread-local).  Zero-sample / zero-ray inputs are not errors.
+ */
+#ifndef FSNERF_HIP_H
+#define FSNERF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* fsn_stream_t; /* hipStream_t */
+
+#define FSN_OK 0
+#define FSN_E_INVALID (-1)     /* bad argument (null pointer, negative size, ...) */
+#define FSN_E_UNSUPPORTED (-2) /* shape outside what the kernels are built for */
+#define FSN_E_HIP (-3)         /* HIP runtime error (launch, no device, ...) */
+
+/* arithmetic of the MLP contractions */
+#define FSN_PREC_BF16X3 0 /* split-bf16 (hi+lo) x 3 MFMA passes, fp32 accumulate: ~fp32 accuracy */
+#define FSN_PREC_BF16 1   /* single bf16 MFMA pass, fp32 accumulate (BASELINE config 5) */
+
+int fsn_version(void);
+const char* fsn_last_error(void);
+/* number of compute units of the current device (grid sizing), or negative on error */
+int fsn_device_cus(void);
+
+/* ---- a1: get_rays(pose, hwf, device)                     src/utils/utilities.py:36-82
+ * pose_host: 12 floats = rows 0..2 of the camera-to-world matrix, row-major [3][4].
+ * Rows [row0, row0+nrows) of the H x W image are produced (row0=0,nrows=H for a frame; a
+ * rank renders its own row block).  rays_o, rays_d: [nrows*W, 3].  focal / near are doubles
+ * because the reference forms W*0.5, 2*near and 1/(W/(2 focal)) in Python double precision
+ * before rounding to float32 (utilities.py:67, 104-114). */
+int fsn_get_rays(const float* pose_host, int H, int W, double focal, int row0, int nrows,
+                 float* rays_o, float* rays_d, fsn_stream_t stream);
+
+/* ---- a2: to_ndc(rays_o, rays_d, hwf, near)               src/utils/utilities.py:84-120 */
+int fsn_to_ndc(const float* rays_o, const float* rays_d, int64_t n, int H, int W, double focal,
+               double near, float* ndc_o, float* ndc_d, fsn_stream_t stream);
+
+/* ---- a4: PositionalEncoder.forward(x)                    src/core/models.py:43-50
+ * x [n, d_in] -> out [n, d_in*(1+2*n_freqs)], block order x, sin f0, cos f0, sin f1, ...
+ * freqs_host: n_freqs float32 values (models.py:31-34).  mask (device, [d_out]) may be NULL:
+ * the build's frequency mask, multiplied onto the encoded features (mask==1 = reference). */
+int fsn_posenc_fwd(const float* x, int64_t n, int d_in, int n_freqs, const float* freqs_host,
+                   const float* mask, float* out, fsn_stream_t stream);
+
+/* ---- a8: the `estimator.sampling` slot                   src/render/rendering.py:66-74
+ * Fixed-count stratified sampler (build's definition): S+1 sorted interval
+ * edges per ray, edges [R, S+1].  u_mode 0: u ignored, e_i = near + i*step;
+ * 1: u [R], one shift per ray, e_i = near + (i+u_r)*step; 2: u [R, S+1], per-edge jitter. */
+int fsn_stratified_edges(float near, float far, int S, int64_t R, const float* u, int u_mode,
+                         float* edges, fsn_stream_t stream);
+/* edges [R, S+1] -> packed (ray_indices int64 [R*S], t_starts [R*S], t_ends [R*S]) */
+int fsn_edges_to_packed(const float* edges, int64_t R, int S, int64_t* ray_indices,
+                        float* t_starts, float* t_ends, fsn_stream_t stream);
+/* hierarchical "+n_imp" step: inverse-CDF samples of the piecewise-constant pdf given by the
+ * coarse weights [R,S] over edges [R,S+1], merged with the coarse edges and sorted:
+ * edges_out [R, S+1+n_imp].  u [R, n_imp] or NULL (deterministic linspace(0,1,n_imp)). */
+int fsn_sample_pdf_merge(const float* edges, const float* weights, int64_t R, int S, int n_imp,
+                         const float* u, float* edges_out, fsn_stream_t stream);
+
+/* ---- a7: nerfacc.volrend.rendering arithmetic            call site src/render/rendering.py:89-96
+ * Dense form: every ray has S samples; sigmas [R,S], rgbs [R,S,3], t_starts/t_ends [R,S].
+ * colors [R,3], opacity [R], depth [R]; weights/alphas/trans [R,S] may be NULL.
+ * bkgd_host: 3 floats (render_bkgd) or NULL (no background term). */
+int fsn_composite_fwd(const float* sigmas, const float* rgbs, const float* t_starts,
+                      const float* t_ends, int64_t R, int S, const float* bkgd_host,
+                      float* colors, float* opacity, float* depth, float* weights,
+                      float* alphas, float* trans, fsn_stream_t stream);
+/* Packed (variable samples per ray) form with the reference's own contract: samples of a ray
+ * are contiguous; ray_indices int64 [N] non-decreasing.  Rays with no sample get the
+ * background colour, zero opacity and zero depth (reference fallback, rendering.py:97-103). */
+int fsn_composite_packed_fwd(const float* sigmas, const float* rgbs, const float* t_starts,
+                             const float* t_ends, const int64_t* ray_indices, int64_t N,
+                             int64_t R, const float* bkgd_host, float* colors, float* opacity,
+                             float* depth, float* weights, float* alphas, float* trans,
+                             fsn_stream_t stream);
+
+/* ---- a5: NeRF(d_pos,d_dir,n_layers,d_hidden,skip,...).forward(x, dirs)   src/core/models.py:53-143 */
+typedef struct fsn_mlp_desc {
+  int32_t n_layers;    /* hidden layers before the bottleneck (8)                 */
+  int32_t d_hidden;    /* 256 or 128                                              */
+  uint32_t skip_mask;  /* bit i set: x_in is concatenated after layer i (i < n_layers-1) */
+  int32_t n_freqs_pos; /* <= 10 */
+  int32_t n_freqs_dir; /* <= 4  */
+  float freqs_pos[16]; /* models.py:31-34 values */
+  float freqs_dir[16];
+} fsn_mlp_desc;
+
+/* Size in bytes of the packed-weights blob for (desc, prec); negative on error. */
+int64_t fsn_mlp_blob_bytes(const fsn_mlp_desc* desc, int prec);
+/* Pack a reference-format state_dict into the MFMA streaming layout (DESIGN.md "weight blob").
+ * weights / biases: HOST arrays of n_layers+4 DEVICE pointers in the order
+ *   layers.0 .. layers.{n_layers-1}, sigma, connection, branch, rgb
+ * each weight row-major [out, in] exactly as in the state_dict (src/core/models.py:96-108). */
+int fsn_mlp_pack(const fsn_mlp_desc* desc, int prec, const float* const* weights_host_of_dev,
+                 const float* const* biases_host_of_dev, void* blob, fsn_stream_t stream);
+/* Same packing on the CPU with HOST pointers and a HOST blob (format tests, no GPU needed). */
+int fsn_mlp_pack_host(const fsn_mlp_desc* desc, int prec, const float* const* weights_host,
+                      const float* const* biases_host, void* blob_host);
+/* x [n,3]; dirs [n,3] or NULL.  out [n,4]=[r,g,b,sigma] when dirs != NULL, else [n,1]=sigma.
+ * pos_mask [3*(1+2*n_freqs_pos)] / dir_mask [3*(1+2*n_freqs_dir)] device pointers or NULL. */
+int fsn_mlp_fwd(const fsn_mlp_desc* desc, int prec, const void* blob, const float* x,
+                const float* dirs, const float* pos_mask, const float* dir_mask, int64_t n,
+                float* out, fsn_stream_t stream);
+
+/* ---- a6: render_rays(rays_o, rays_d, estimator, model, ...)   src/render/rendering.py:25-107
+ * The whole path fused in one launch for the fixed-count sampler: stratified edges ->
+ * [density pass of the coarse net -> weights -> sample_pdf -> sorted union] -> full pass of
+ * the fine net -> volume integration.  n_imp == 0 renders the S coarse intervals with
+ * `blob_fine` only (blob_coarse unused).  S_out = S + n_imp intervals per ray.
+ *   u_mode/u as fsn_stratified_edges; u_fine [R,n_imp] or NULL (deterministic).
+ *   outputs: colors [R,3], opacity [R], depth [R]; optional (NULL to skip):
+ *   weights, alphas, trans, sigmas [R,S_out], rgbs [R,S_out,3], edges_out [R,S_out+1],
+ *   weights_coarse [R,S] (only written when n_imp > 0). */
+typedef struct fsn_render_args {
+  const float* rays_o; /* [R,3] */
+  const float* rays_d; /* [R,3] */
+  int64_t R;
+  float near, far;
+  int32_t S, n_imp;
+  int32_t u_mode;
+  const float* u;
+  const float* u_fine;
+  const float* pos_mask;
+  const float* dir_mask;
+  float bkgd[3];
+  float* colors;
+  float* opacity;
+  float* depth;
+  float* weights;
+  float* alphas;
+  float* trans;
+  float* sigmas;
+  float* rgbs;
+  float* edges_out;
+  float* weights_coarse;
+} fsn_render_args;
+
+int fsn_render_rays_fused(const fsn_mlp_desc* desc, int prec, const void* blob_coarse,
+                          const void* blob_fine, const fsn_render_args* args_host,
+                          fsn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FSNERF_HIP_H */

@@ -1,0 +1,388 @@
+"""GPU parity tests: every HIP entry point (through the C-ABI, via the Python host layer)
+against the CPU oracle on the same seeded inputs, and against the committed golden vectors.
+
+Tolerances (north_star: 1e-4 relative fp32 on rgb_map, depth_map, weights):
+  RTOL = 1e-4 with a small absolute floor (values that are ~0 have no meaningful relative error):
+  rgb/opacity/weights ATOL 1e-5 (quantities in [0,1]), depth ATOL 1e-4 (metres, range ~6),
+  raw sigma ATOL 1e-4 * max|sigma| (sigma is a 256-term dot product with cancellation).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fsnerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import fs_nerf_amd  # noqa: F401
+    from fs_nerf_amd import _lib
+    _lib.lib()  # fail loudly if the HIP library is missing
+    return torch.device("cuda:0")
+
+
+def close(a, b, rtol=RTOL, atol=1e-5, what=""):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
+    err = np.abs(a - b) - (atol + rtol * np.abs(b))
+    if not (err <= 0).all():
+        i = np.unravel_index(np.argmax(err), err.shape)
+        raise AssertionError(f"{what}: max violation at {i}: got {a[i]!r} want {b[i]!r} "
+                             f"(|diff| {abs(a[i] - b[i]):.3e}, {(err > 0).sum()} of {err.size} out of tolerance)")
+
+
+def load_sd(golden_dir, tag, sigma64=True):
+    g = np.load(os.path.join(golden_dir, f"g4_nerf_{tag}.npz"))
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    if sigma64:
+        sd["sigma.weight"] = sd["sigma.weight"] * 64.0
+        sd["sigma.bias"] = sd["sigma.bias"] + 1.0
+    return g, sd
+
+
+def make_model(sd, n_layers, d_hidden, skip, dev, nf=10, nfd=4, precision="bf16x3"):
+    from fs_nerf_amd.core.models import NeRF
+    m = NeRF(3, 3, n_layers, d_hidden, skip, precision=precision,
+             pos_fn={"n_freqs": nf, "log_space": True}, dir_fn={"n_freqs": nfd, "log_space": True})
+    m.load_state_dict(sd)
+    return m.to(dev).eval()
+
+
+CFG = {"8x256": dict(n_layers=8, skip=[4], n_freqs=10, n_freqs_dir=4, log_space=True),
+       "4x128": dict(n_layers=4, skip=[4], n_freqs=10, n_freqs_dir=4, log_space=True)}
+DIMS = {"8x256": (8, 256), "4x128": (4, 128)}
+
+
+# ------------------------------------------------------------------ a1/a2/a3 rays
+@pytest.mark.parametrize("pname", ["identity", "orbit0", "orbit3x4", "random"])
+@pytest.mark.parametrize("hname", ["small", "lego100"])
+def test_get_rays_to_ndc_golden(dev, golden_dir, pname, hname):
+    from fs_nerf_amd.utils import utilities as U
+    g = np.load(os.path.join(golden_dir, "g1_rays.npz"))
+    key = f"{pname}_{hname}"
+    hwf = (int(g[key + "_hwf"][0]), int(g[key + "_hwf"][1]), float(g[key + "_hwf"][2]))
+    o, d = U.get_rays(torch.from_numpy(g[key + "_pose"]), hwf, dev)
+    assert o.shape == (hwf[0], hwf[1], 3) and d.shape == o.shape
+    close(o, g[key + "_o"], rtol=0, atol=0, what="origins")
+    close(d, g[key + "_d"], rtol=1e-6, atol=1e-7, what="dirs")
+    no, nd = U.to_ndc(torch.from_numpy(g[key + "_o"]).to(dev).reshape(-1, 3),
+                      torch.from_numpy(g[key + "_d"]).to(dev).reshape(-1, 3), hwf, 1.0)
+    ok = np.isfinite(g[key + "_ndc_o"]).all(-1) & np.isfinite(g[key + "_ndc_d"]).all(-1)
+    # the projection divides by o_z / d_z: compare where the reference itself is well conditioned
+    ok &= (np.abs(g[key + "_ndc_o"]).max(-1) < 1e3) & (np.abs(g[key + "_ndc_d"]).max(-1) < 1e3)
+    close(no.cpu().numpy()[ok], g[key + "_ndc_o"][ok], rtol=1e-4, atol=1e-4, what="ndc_o")
+    close(nd.cpu().numpy()[ok], g[key + "_ndc_d"][ok], rtol=1e-4, atol=1e-4, what="ndc_d")
+
+
+def test_get_rays_row_blocks_and_800(dev):
+    from fs_nerf_amd import ops
+    pose = O.pose_from_spherical(4.0311289, 50.0, 77.0)
+    H = W = 800
+    focal = 1111.111
+    o, d = ops.get_rays(pose, H, W, focal, dev)
+    ro, rd = O.get_rays(pose, (H, W, focal))
+    close(d.reshape(H, W, 3), rd, rtol=1e-6, atol=1e-7, what="800x800 dirs")
+    o2, d2 = ops.get_rays(pose, H, W, focal, dev, row0=300, nrows=100)  # a rank's row block
+    assert torch.equal(d2, d.reshape(H, W, 3)[300:400].reshape(-1, 3))
+    assert torch.equal(o2, o.reshape(H, W, 3)[300:400].reshape(-1, 3))
+    from fs_nerf_amd.utils import utilities as U
+    assert [c.shape[0] for c in U.get_chunks(o, 250000)] == [250000, 250000, 140000]
+    with pytest.raises(RuntimeError):
+        U.get_rays(pose, (4, 4, 2.0), torch.device("cpu"))
+
+
+# ------------------------------------------------------------------ a4 encoder
+@pytest.mark.parametrize("n,ls", [(10, True), (4, True), (10, False), (4, False), (0, True)])
+def test_posenc(dev, golden_dir, n, ls):
+    from fs_nerf_amd.core.models import PositionalEncoder
+    g = np.load(os.path.join(golden_dir, "g3_posenc.npz"))
+    enc = PositionalEncoder(3, n, ls)
+    x = torch.from_numpy(g["x"]).to(dev)
+    y = enc(x)
+    assert y.shape == (256, enc.d_output)
+    if n > 0:
+        close(y, g[f"pe_n{n}_log{int(ls)}"], rtol=0, atol=2e-6, what="posenc vs reference golden")
+        m = O.freq_mask(3, n, 0.45)
+        close(enc(x, m.to(dev)), O.posenc(torch.from_numpy(g["x"]), n, ls, m), rtol=0, atol=2e-6, what="masked")
+    else:
+        assert torch.equal(y, x)
+    assert enc(torch.zeros(0, 3, device=dev)).shape == (0, enc.d_output)
+
+
+# ------------------------------------------------------------------ a8 sampler
+@pytest.mark.parametrize("mode", ["none", "ray", "edge"])
+@pytest.mark.parametrize("S", [64, 100, 7])
+def test_stratified_edges(dev, mode, S):
+    from fs_nerf_amd import ops
+    R = 333
+    gen = torch.Generator().manual_seed(5)
+    u = None if mode == "none" else (torch.rand(R, generator=gen) if mode == "ray" else torch.rand(R, S + 1, generator=gen))
+    want = O.stratified_edges(2.0, 6.0, S, R, u)
+    got = ops.stratified_edges(2.0, 6.0, S, R, None if u is None else u.to(dev), dev)
+    close(got, want, rtol=0, atol=1e-6, what="edges")
+    assert bool((got[:, 1:] >= got[:, :-1]).all())
+    ri, t0, t1 = ops.edges_to_packed(got)
+    wri, wt0, wt1 = O.edges_to_packed(got.cpu())
+    assert ri.dtype == torch.int64 and torch.equal(ri.cpu(), wri)
+    assert torch.equal(t0.cpu(), wt0) and torch.equal(t1.cpu(), wt1)
+
+
+@pytest.mark.parametrize("S,NI,det", [(64, 128, True), (64, 128, False), (32, 16, False), (128, 256, True), (5, 3, False)])
+def test_sample_pdf_merge(dev, S, NI, det):
+    from fs_nerf_amd import ops
+    R = 257
+    gen = torch.Generator().manual_seed(11)
+    edges = O.stratified_edges(2.0, 6.0, S, R, torch.rand(R, generator=gen))
+    w = torch.rand(R, S, generator=gen) ** 4
+    w[::7] = 0.0        # rays with no mass: uniform pdf
+    w[3, S // 2:] = -0.2  # negative weights are clamped
+    u = None if det else torch.rand(R, NI, generator=gen)
+    want = O.merge_edges(edges, O.sample_pdf(edges, w, NI, u))
+    got = ops.sample_pdf_merge(edges.to(dev), w.to(dev), NI, None if u is None else u.to(dev))
+    assert got.shape == (R, S + 1 + NI)
+    assert bool((got[:, 1:] >= got[:, :-1]).all()), "sorted union"
+    # a sample whose cdf gap sits exactly at the 1e-5 'denom' threshold may flip branch: allow a handful
+    bad = (got.cpu() - want).abs() > (1e-5 + 1e-5 * want.abs())
+    assert bad.float().mean().item() < 1e-3, f"{int(bad.sum())} of {bad.numel()} differ"
+
+
+# ------------------------------------------------------------------ a7 compositing
+@pytest.mark.parametrize("S", [64, 192, 5, 384, 1])
+@pytest.mark.parametrize("white", [False, True])
+def test_composite_dense(dev, S, white):
+    from fs_nerf_amd import ops
+    R = 130
+    gen = torch.Generator().manual_seed(S)
+    edges = O.stratified_edges(2.0, 6.0, S, R, torch.rand(R, generator=gen))
+    t0, t1 = edges[:, :-1].contiguous(), edges[:, 1:].contiguous()
+    sig = torch.randn(R, S, generator=gen) * 8.0 + 4.0  # raw sigma, negatives allowed (models.py:127)
+    rgb = torch.rand(R, S, 3, generator=gen)
+    bk = torch.ones(3) * float(white)
+    wc, wo, wd, wex = O.composite(sig.double(), rgb.double(), t0.double(), t1.double(), bk.double())
+    c, o, d, ex = ops.composite(sig.to(dev), rgb.to(dev), t0.to(dev), t1.to(dev), bk)
+    assert c.shape == (R, 3) and o.shape == (R, 1) and d.shape == (R, 1)
+    scale = float(wex["weights"].abs().max())  # negative sigma can push T above 1
+    close(ex["weights"], wex["weights"], atol=1e-5 * max(scale, 1.0), what="weights")
+    close(ex["alphas"], wex["alphas"], atol=1e-5, what="alphas")
+    close(ex["trans"], wex["trans"], atol=1e-5 * float(wex["trans"].abs().max()), what="trans")
+    close(c, wc, atol=1e-5 * max(scale, 1.0), what="colors")
+    close(o, wo, atol=1e-5 * max(scale, 1.0), what="opacity")
+    ok = (wo.abs() > 1e-3).squeeze(-1)  # depth divides by opacity
+    close(d[ok.to(dev)], wd[ok], atol=1e-4, what="depth")
+
+
+def test_composite_packed_ragged(dev):
+    from fs_nerf_amd.render import rendering as Rm
+    gen = torch.Generator().manual_seed(2)
+    counts = torch.tensor([0, 3, 64, 0, 1, 200, 17, 0])  # empty rays in front, middle and at the end
+    R = len(counts)
+    ri = torch.repeat_interleave(torch.arange(R), counts)
+    N = int(counts.sum())
+    t0 = torch.rand(N, generator=gen) * 0.01 + torch.arange(N) * 0.02
+    t1 = t0 + 0.02
+    sig = torch.rand(N, generator=gen) * 30.0
+    rgb = torch.rand(N, 3, generator=gen)
+    bk = torch.tensor([1.0, 1.0, 1.0])
+    want = O.rendering_packed(t0, t1, ri, R, lambda a, b, c: (rgb, sig), bk)
+    got = Rm.rendering(t0.to(dev), t1.to(dev), ri.to(dev), R, lambda a, b, c: (rgb.to(dev), sig.to(dev)), bk.to(dev))
+    for k in range(3):
+        close(got[k], want[k], atol=1e-5 if k != 2 else 1e-4, what=f"packed out {k}")
+    close(got[3]["weights"], want[3]["weights"], what="packed weights")
+    # rays without samples: background colour, zero opacity and depth (rendering.py:97-103)
+    for r in (0, 3, 7):
+        assert got[0][r].tolist() == [1.0, 1.0, 1.0] and float(got[1][r]) == 0.0 and float(got[2][r]) == 0.0
+    with pytest.raises(AssertionError):
+        Rm.rendering(t0.to(dev), t1.to(dev), ri.to(dev), R, lambda a, b, c: (rgb.to(dev)[:, :2], sig.to(dev)), None)
+    # zero samples in total
+    e = torch.zeros(0, device=dev)
+    out = Rm.rendering(e, e, torch.zeros(0, dtype=torch.int64, device=dev), 4,
+                       lambda a, b, c: (torch.zeros(0, 3, device=dev), e), torch.zeros(3, device=dev))
+    assert float(out[0].abs().max()) == 0.0 and out[0].shape == (4, 3)
+
+
+# ------------------------------------------------------------------ a5 MLP
+@pytest.mark.parametrize("tag", ["8x256", "4x128"])
+def test_nerf_forward_golden(dev, golden_dir, tag):
+    g, sd = load_sd(golden_dir, tag, sigma64=False)
+    m = make_model(sd, *DIMS[tag], [4], dev)
+    x, d = torch.from_numpy(g["x"]).to(dev), torch.from_numpy(g["dirs"]).to(dev)
+    with torch.no_grad():
+        y4, y1 = m(x, d), m(x)
+    assert y4.shape == (256, 4) and y1.shape == (256, 1)
+    s_atol = 1e-4 * float(np.abs(g["y_sigma"]).max())
+    close(y4[:, :3], g["y_full"][:, :3], atol=1e-5, what="rgb vs reference golden")
+    close(y4[:, 3], g["y_full"][:, 3], atol=s_atol, what="sigma vs reference golden")
+    close(y1, g["y_sigma"], atol=s_atol, what="density-only vs reference golden")
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    sd2["sigma.weight"] *= 64.0
+    sd2["sigma.bias"] += 1.0
+    m.load_state_dict(sd2)  # parameters changed -> repacked
+    with torch.no_grad():
+        y4b = m(x, d)
+    close(y4b[:, 3], g["y_full_sigma64"][:, 3], atol=1e-4 * float(np.abs(g["y_full_sigma64"][:, 3]).max()),
+          what="sigma64 vs reference golden")
+    assert set(m.state_dict().keys()) == set(sd.keys())
+
+
+@pytest.mark.parametrize("tag,n", [("8x256", 1), ("8x256", 127), ("8x256", 129), ("4x128", 1000), ("8x256", 70001)])
+def test_nerf_forward_sizes_vs_oracle(dev, golden_dir, tag, n):
+    _, sd = load_sd(golden_dir, tag)
+    m = make_model(sd, *DIMS[tag], [4], dev)
+    gen = torch.Generator().manual_seed(n)
+    x = torch.rand(n, 3, generator=gen) * 3.0 - 1.5
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    want = O.nerf_forward(sd64, x.double(), d.double(), **CFG[tag])
+    with torch.no_grad():
+        got = m(x.to(dev), d.to(dev))
+        got1 = m(x.to(dev))
+    s_atol = 1e-4 * float(want[:, 3].abs().max())
+    close(got[:, :3], want[:, :3], atol=1e-5, what="rgb")
+    close(got[:, 3], want[:, 3], atol=s_atol, what="sigma")
+    close(got1[:, 0], want[:, 3], atol=s_atol, what="density-only")
+    assert m(torch.zeros(0, 3, device=dev), torch.zeros(0, 3, device=dev)).shape == (0, 4)
+
+
+def test_nerf_forward_mask_skips_and_bf16(dev):
+    sd = O.init_nerf_state_dict(6, 128, [1, 3], 7, 3, seed=7)
+    m = make_model(sd, 6, 128, [1, 3], dev, nf=7, nfd=3)
+    pm, dm = O.freq_mask(3, 7, 0.6), O.freq_mask(3, 3, 0.5)
+    m.set_freq_mask(pm, dm)
+    gen = torch.Generator().manual_seed(9)
+    x = torch.rand(500, 3, generator=gen) * 2 - 1
+    d = torch.nn.functional.normalize(torch.randn(500, 3, generator=gen), dim=-1)
+    want = O.nerf_forward({k: v.double() for k, v in sd.items()}, x.double(), d.double(), n_layers=6, skip=[1, 3],
+                          n_freqs=7, n_freqs_dir=3, pos_mask=pm.double(), dir_mask=dm.double())
+    with torch.no_grad():
+        got = m(x.to(dev), d.to(dev))
+    close(got[:, :3], want[:, :3], atol=1e-5, what="masked rgb")
+    close(got[:, 3], want[:, 3], atol=1e-4 * float(want[:, 3].abs().max()), what="masked sigma")
+    # single-pass bf16 mode (BASELINE config 5): relaxed tolerance 2e-2 absolute on rgb
+    m16 = make_model(sd, 6, 128, [1, 3], dev, nf=7, nfd=3, precision="bf16")
+    m16.set_freq_mask(pm, dm)
+    with torch.no_grad():
+        got16 = m16(x.to(dev), d.to(dev))
+    close(got16[:, :3], want[:, :3], rtol=0, atol=2e-2, what="bf16 rgb")
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m(x.to(dev), d.to(dev))
+
+
+# ------------------------------------------------------------------ a6 whole path
+def _rays(R, seed, hw=100, focal=138.88887889922103):
+    gen = torch.Generator().manual_seed(seed)
+    pose = O.pose_from_spherical(4.0311289, 50.0, float(torch.rand(1, generator=gen)) * 360.0)
+    o, d = O.get_rays(pose, (hw, hw, focal))
+    idx = torch.randperm(hw * hw, generator=gen)[:R]
+    return o.reshape(-1, 3)[idx].contiguous(), d.reshape(-1, 3)[idx].contiguous(), gen
+
+
+def _check_render(out, want, what):
+    (rgb, op, dep, ex), ri, tv = out
+    (wrgb, wop, wdep, wex), wri, wtv = want
+    close(ex["edges"], wex["edges"], rtol=1e-5, atol=1e-5, what=what + " edges")
+    close(ex["weights"].reshape(wex["weights"].shape), wex["weights"], atol=1e-5, what=what + " weights")
+    close(rgb, wrgb, atol=1e-5, what=what + " rgb_map")
+    close(op, wop, atol=1e-5, what=what + " opacity")
+    close(dep, wdep, atol=1e-4, what=what + " depth_map")
+    assert torch.equal(ri.cpu(), wri)
+    close(tv, wtv, rtol=1e-5, atol=1e-5, what=what + " t_vals")
+
+
+@pytest.mark.parametrize("tag,R,S,white,jit", [("4x128", 4096, 64, False, "ray"), ("4x128", 100, 64, True, "none"),
+                                               ("8x256", 257, 64, True, "edge"), ("8x256", 64, 100, False, "ray")])
+def test_render_rays_coarse_only(dev, golden_dir, tag, R, S, white, jit):
+    from fs_nerf_amd.render import rendering as Rm
+    _, sd = load_sd(golden_dir, tag)
+    m = make_model(sd, *DIMS[tag], [4], dev)
+    o, d, gen = _rays(R, 42)
+    u = None if jit == "none" else (torch.rand(R, generator=gen) if jit == "ray" else torch.rand(R, S + 1, generator=gen))
+    sd64 = {k: v.double() for k, v in sd.items()}
+    want = O.render_rays_oracle(o.double(), d.double(), sd64, None, CFG[tag], near=2.0, far=6.0, n_samples=S,
+                                u=None if u is None else u.double(), white_bkgd=white)
+    est = Rm.StratifiedEstimator(2.0, 6.0, S, 0)
+    out = Rm.render_rays(o, d, est, m, train=False, white_bkgd=white, device=dev, u=None if u is None else u.to(dev))
+    _check_render(out, want, f"{tag} S={S}")
+    assert out[0][3]["sigmas"].shape == (R * S,) and out[0][3]["rgbs"].shape == (R * S, 3)
+
+
+@pytest.mark.parametrize("tag,R,S,NI,two_nets", [("8x256", 130, 64, 128, True), ("4x128", 1001, 64, 128, False),
+                                                 ("4x128", 33, 128, 256, True)])
+def test_render_rays_hierarchical(dev, golden_dir, tag, R, S, NI, two_nets):
+    from fs_nerf_amd.render import rendering as Rm
+    _, sd = load_sd(golden_dir, tag)
+    sd_f = None
+    if two_nets:
+        sd_f = O.init_nerf_state_dict(DIMS[tag][0], DIMS[tag][1], [4], 10, 4, seed=43)
+        sd_f["sigma.weight"] = sd_f["sigma.weight"] * 64.0
+        sd_f["sigma.bias"] = sd_f["sigma.bias"] + 1.0
+    mc = make_model(sd, *DIMS[tag], [4], dev)
+    mf = make_model(sd_f, *DIMS[tag], [4], dev) if two_nets else None
+    o, d, gen = _rays(R, 7)
+    u = torch.rand(R, generator=gen)
+    uf = torch.rand(R, NI, generator=gen)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    sdf64 = None if sd_f is None else {k: v.double() for k, v in sd_f.items()}
+    want = O.render_rays_oracle(o.double(), d.double(), sd64, sdf64, CFG[tag], near=2.0, far=6.0, n_samples=S,
+                                n_importance=NI, u=u.double(), u_fine=uf.double(), white_bkgd=True)
+    est = Rm.StratifiedEstimator(2.0, 6.0, S, NI)
+    out = Rm.render_rays(o, d, est, mc, train=False, white_bkgd=True, device=dev, model_fine=mf, u=u.to(dev),
+                         u_fine=uf.to(dev))
+    close(out[0][3]["weights_coarse"], want[0][3]["weights_coarse"], atol=1e-5, what="coarse weights")
+    _check_render(out, want, f"{tag} {S}+{NI}")
+
+
+def test_render_rays_generic_model_matches_fused(dev, golden_dir):
+    """Any callable model goes through the unfused HIP sampler/compositor kernels (the reference's
+    closure structure); it must agree with the fused launch."""
+    from fs_nerf_amd.render import rendering as Rm
+    _, sd = load_sd(golden_dir, "4x128")
+    m = make_model(sd, 4, 128, [4], dev)
+
+    class Wrapped(torch.nn.Module):  # not a fs_nerf_amd NeRF -> generic path
+        def forward(self, x, dirs=None):
+            return m(x, dirs)
+
+    o, d, gen = _rays(300, 3)
+    u, uf = torch.rand(300, generator=gen).to(dev), torch.rand(300, 128, generator=gen).to(dev)
+    est = Rm.StratifiedEstimator(2.0, 6.0, 64, 128)
+    with torch.no_grad():
+        a = Rm.render_rays(o, d, est, m, device=dev, u=u, u_fine=uf)
+        b = Rm.render_rays(o, d, est, Wrapped().eval(), device=dev, u=u, u_fine=uf)
+    close(a[0][0], b[0][0], atol=1e-5, what="rgb fused vs generic")
+    close(a[0][2], b[0][2], atol=1e-4, what="depth fused vs generic")
+    close(a[2], b[2], rtol=1e-5, atol=1e-5, what="t_vals fused vs generic")
+    assert torch.equal(a[1], b[1])
+
+
+def test_render_frame_and_properties(dev, golden_dir):
+    """Full-size properties: an 800x800 frame (BASELINE config 3 geometry, 4x128 net to keep the
+    oracle out of it) — finite, opacity = sum of weights, colours inside the convex hull of
+    [bkgd, rgbs], deterministic, and chunking-invariant."""
+    from fs_nerf_amd.render import rendering as Rm
+    _, sd = load_sd(golden_dir, "4x128")
+    m = make_model(sd, 4, 128, [4], dev)
+    est = Rm.StratifiedEstimator(2.0, 6.0, 64, 128)
+    pose = O.pose_from_spherical(4.0311289, 50.0, 30.0)
+    hwf = (800, 800, 1111.111)
+    with torch.no_grad():
+        img, depth = Rm.render_frame(hwf, 2.0, 6.0, pose, 320000, est, m, white_bkgd=True, device=dev)
+        img2, depth2 = Rm.render_frame(hwf, 2.0, 6.0, pose, 100001, est, m, white_bkgd=True, device=dev)
+    assert img.shape == (800, 800, 3) and depth.shape == (800, 800)
+    assert bool(torch.isfinite(img).all()) and bool(torch.isfinite(depth).all())
+    assert torch.equal(img, img2) and torch.equal(depth, depth2), "chunking must not change results"
+    assert float(depth.min()) >= 2.0 and float(depth.max()) <= 6.0
+    assert float(img.min()) >= -1e-4 and float(img.max()) <= 1.0 + 1e-4
+    o, d = Rm.U.get_rays(pose, hwf, dev)
+    out = Rm.render_rays(o.reshape(-1, 3)[:5000], d.reshape(-1, 3)[:5000], est, m, white_bkgd=True, device=dev)
+    (rgb, op, _, ex), _, _ = out
+    close(ex["weights"].reshape(5000, 192).sum(-1, keepdim=True), op, atol=1e-5, what="opacity = sum weights")
+    assert torch.equal(rgb, img.reshape(-1, 3)[:5000])

@@ -1,0 +1,200 @@
+"""CPU (no GPU): the packed-weights blob and the kernel's register dataflow.
+
+`fsn_mlp_pack_host` (the same index code as the device packer) packs a reference-format
+state_dict; a NumPy model of v_mfma_f32_32x32x16_bf16's documented lane layouts
+(cdna_hip_programming.md section 3) then replays exactly what fs-nerf_amd/csrc/mlp_dev.hpp does for one
+wavefront of 32 samples — encoding slots, unit order, accumulator-as-B-operand chaining,
+fp32 heads — and the result must equal the oracle's NeRF forward.  This pins the blob
+format and the chaining rule without a GPU."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fs_nerf_amd
+from fs_nerf_amd import _lib as L
+from fs_nerf_amd import ops
+from oracle import fsnerf_oracle as O
+
+
+def bf16_to_f32(u16: np.ndarray) -> np.ndarray:
+    return (u16.astype(np.uint32) << 16).view(np.float32)
+
+
+def pack_host(sd, n_layers, d_hidden, skip, nf, nfd, prec):
+    fp = O.pe_freqs(nf, True).tolist()
+    fd = O.pe_freqs(nfd, True).tolist()
+    desc = ops.make_desc(n_layers, d_hidden, skip, fp, fd)
+    nbytes = L.lib().fsn_mlp_blob_bytes(C.byref(desc), prec)
+    assert nbytes > 0
+    ws, bs = ops.sd_tensor_lists(sd, n_layers)
+    ws = [np.ascontiguousarray(w.numpy(), dtype=np.float32) for w in ws]
+    bs = [np.ascontiguousarray(b.numpy(), dtype=np.float32) for b in bs]
+    n = n_layers + 4
+    Wp = (C.c_void_p * n)(*[w.ctypes.data for w in ws])
+    Bp = (C.c_void_p * n)(*[b.ctypes.data for b in bs])
+    blob = np.zeros(nbytes, dtype=np.uint8)
+    L.check(L.lib().fsn_mlp_pack_host(C.byref(desc), prec, Wp, Bp, blob.ctypes.data), "fsn_mlp_pack_host")
+    return blob
+
+
+class Emu:
+    """One wavefront (64 lanes: sample r = lane & 31, half h = lane >> 5) of mlp_dev.hpp."""
+
+    def __init__(self, blob, prec):
+        hw = blob[:256].view(np.uint32)
+        assert hw[0] == 0x4E53460A
+        self.prec, self.L, self.D = int(hw[2]), int(hw[3]), int(hw[4])
+        self.skip_mask, self.nf, self.nfd = int(hw[5]), int(hw[6]), int(hw[7])
+        self.units_total, self.nph_full, self.nph_density = int(hw[8]), int(hw[9]), int(hw[10])
+        aux_off, aux_floats, stream_off = int(hw[11]), int(hw[12]), int(hw[13])
+        self.aux = blob[aux_off:aux_off + 4 * aux_floats].view(np.float32)
+        self.stream = blob[stream_off:]
+        self.ub = 2048 if prec == 0 else 1024
+        self.unit = 0
+        self.NT = self.D // 32
+
+    def a_frag(self):
+        """A operand of the next unit as float64 [lane, j] (hi + lo)."""
+        base = self.unit * self.ub
+        hi = bf16_to_f32(self.stream[base:base + 1024].view(np.uint16)).reshape(64, 8).astype(np.float64)
+        if self.prec == 0:
+            hi = hi + bf16_to_f32(self.stream[base + 1024:base + 2048].view(np.uint16)).reshape(64, 8)
+        self.unit += 1
+        return hi
+
+    @staticmethod
+    def mfma(afrag, bfrag, acc):
+        """acc [16 regs, 64 lanes] += A.B with the 32x32x16 lane maps."""
+        A = np.zeros((32, 16))
+        B = np.zeros((16, 32))
+        for lane in range(64):
+            r, h = lane & 31, lane >> 5
+            A[r, 8 * h:8 * h + 8] = afrag[lane]
+            B[8 * h:8 * h + 8, r] = bfrag[lane]
+        Dm = A @ B
+        for lane in range(64):
+            col, h = lane & 31, lane >> 5
+            for reg in range(16):
+                acc[reg, lane] += Dm[(reg & 3) + 8 * (reg >> 2) + 4 * h, col]
+        return acc
+
+    def encode(self, xyz, n_freqs, freqs, mask, nks):
+        slots = 8 * nks
+        v = np.zeros((64, slots))
+        P = 3 * n_freqs
+        for lane in range(64):
+            r, h = lane & 31, lane >> 5
+            x = xyz[r]
+            for i in range((slots - 2) // 2):
+                p = 2 * i + h
+                if p < P:
+                    band, coord = divmod(p, 3)
+                    a = np.float32(x[coord]) * np.float32(freqs[band])
+                    v[lane, 2 * i] = np.sin(np.float64(a)) * mask[3 + band * 6 + coord]
+                    v[lane, 2 * i + 1] = np.cos(np.float64(a)) * mask[3 + band * 6 + 3 + coord]
+            v[lane, slots - 2] = (x[2] * mask[2]) if h else (x[0] * mask[0])
+            v[lane, slots - 1] = 0.0 if h else x[1] * mask[1]
+        return [v[:, 8 * k:8 * k + 8] for k in range(nks)]
+
+    def layer(self, nt_out, act, enc, bias_off, relu):
+        outs, accs = [], []
+        for t in range(nt_out):
+            acc = np.zeros((16, 64))
+            for lane in range(64):
+                h = lane >> 5
+                for reg in range(16):
+                    acc[reg, lane] = self.aux[bias_off + 32 * t + 8 * (reg >> 2) + 4 * h + (reg & 3)]
+            for b in list(act) + list(enc):
+                acc = self.mfma(self.a_frag(), b, acc)
+            if relu:
+                acc = np.maximum(acc, 0.0)
+            accs.append(acc)
+            outs.append(acc[0:8].T.copy())   # k-step 2t   : element j = register j
+            outs.append(acc[8:16].T.copy())  # k-step 2t+1 : element j = register 8 + j
+        return outs, accs
+
+    def head(self, accs, w_off, stride_t=32):
+        tot = np.zeros(64)
+        for t, acc in enumerate(accs):
+            for lane in range(64):
+                h = lane >> 5
+                for reg in range(16):
+                    tot[lane] += self.aux[w_off + 32 * t + 8 * (reg >> 2) + 4 * h + (reg & 3)] * acc[reg, lane]
+        return tot[:32] + tot[32:]
+
+    def forward(self, x, dirs, pos_mask, dir_mask):
+        L_, D = self.L, self.D
+        misc = (L_ + 5) * D
+        self.unit = 0
+        pe = self.encode(x, self.nf, self.aux[misc + 4:misc + 20], pos_mask, 4)
+        act, _ = self.layer(self.NT, [], pe, 0, True)
+        for l in range(1, L_):
+            wide = (self.skip_mask >> (l - 1)) & 1
+            act, accs = self.layer(self.NT, act, pe if wide else [], l * D, True)
+        assert self.unit * self.ub == self.nph_density * 16384
+        sigma = self.head(accs, (L_ + 2) * D) + self.aux[misc]
+        if dirs is None:
+            return sigma[:, None]
+        act, _ = self.layer(self.NT, act, [], L_ * D, False)
+        de = self.encode(dirs, self.nfd, self.aux[misc + 20:misc + 36], dir_mask, 2)
+        _, accs = self.layer(self.NT // 2, act, de, (L_ + 1) * D, True)
+        assert self.unit == self.units_total
+        rgb = [1.0 / (1.0 + np.exp(-(self.head(accs, (L_ + 3) * D + c * (D // 2)) + self.aux[misc + 1 + c])))
+               for c in range(3)]
+        return np.stack(rgb + [sigma], axis=-1)
+
+
+def _load_sd(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, f"g4_nerf_{tag}.npz"))
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    return g, sd
+
+
+@pytest.mark.parametrize("tag,n_layers,d_hidden", [("4x128", 4, 128), ("8x256", 8, 256)])
+@pytest.mark.parametrize("prec", [0, 1])
+def test_blob_replays_to_reference_forward(golden_dir, tag, n_layers, d_hidden, prec):
+    g, sd = _load_sd(golden_dir, tag)
+    blob = pack_host(sd, n_layers, d_hidden, [4], 10, 4, prec)
+    emu = Emu(blob, prec)
+    assert emu.L == n_layers and emu.D == d_hidden
+    assert emu.skip_mask == (0b10000 if n_layers > 5 else 0)
+    x, d = g["x"][:32], g["dirs"][:32]
+    ones_p, ones_d = np.ones(64), np.ones(32)
+    y = emu.forward(x, d, ones_p, ones_d)
+    ref = g["y_full"][:32]
+    # prec 0: weights are hi+lo (16 mantissa bits) and activations exact -> ~1e-5; prec 1: bf16 weights
+    tol = 2e-5 if prec == 0 else 2e-2
+    np.testing.assert_allclose(y[:, :3], ref[:, :3], rtol=0, atol=tol)
+    np.testing.assert_allclose(y[:, 3], ref[:, 3], rtol=0, atol=tol)
+    ys = emu.forward(x, None, ones_p, ones_d)
+    np.testing.assert_allclose(ys[:, 0], g["y_sigma"][:32, 0], rtol=0, atol=tol)
+
+
+def test_blob_frequency_mask_and_wide_variants(golden_dir):
+    # skip at two places + a frequency mask: emulator == oracle with the same mask
+    sd = O.init_nerf_state_dict(6, 128, [1, 3], 7, 3, seed=7)
+    blob = pack_host(sd, 6, 128, [1, 3], 7, 3, 0)
+    emu = Emu(blob, 0)
+    assert emu.skip_mask == 0b1010
+    gen = torch.Generator().manual_seed(3)
+    x = torch.rand(32, 3, generator=gen) * 2 - 1
+    d = torch.nn.functional.normalize(torch.randn(32, 3, generator=gen), dim=-1)
+    pm, dm = O.freq_mask(3, 7, 0.6), O.freq_mask(3, 3, 0.5)
+    ref = O.nerf_forward(sd, x.double(), d.double(), n_layers=6, skip=[1, 3], n_freqs=7, n_freqs_dir=3,
+                         pos_mask=pm.double(), dir_mask=dm.double()).numpy()
+    pmk, dmk = np.ones(64), np.ones(32)
+    pmk[:pm.numel()], dmk[:dm.numel()] = pm.numpy(), dm.numpy()
+    y = emu.forward(x.numpy(), d.numpy(), pmk, dmk)
+    np.testing.assert_allclose(y, ref, rtol=0, atol=3e-5)
+
+
+def test_pack_rejects_unsupported_shapes():
+    with pytest.raises(ValueError):
+        ops.make_desc(8, 256, [7], [1.0] * 10, [1.0] * 4)
+    for kw in (dict(n_layers=8, d_hidden=192), dict(n_layers=1, d_hidden=256), dict(n_layers=8, d_hidden=256, nf=11)):
+        desc = ops.make_desc(kw["n_layers"], kw["d_hidden"], [], [1.0] * kw.get("nf", 10), [1.0] * 4)
+        assert L.lib().fsn_mlp_blob_bytes(C.byref(desc), 0) < 0
+        assert len(L.lib().fsn_last_error()) > 0
