@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py — rendered rays/sec of the fused HIP ray-rendering path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N=1 directly; N>1 under torch.distributed.run)
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): synthetic Lego-style
+orbit, 800x800 frames (focal 1111.11, near 2, far 6), 64 coarse + 128 importance samples per ray
+(192 fine intervals), two 8x256 NeRF networks (coarse seed 42, fine seed 43; default nn.Linear init,
+sigma head scaled so that alpha is not ~0), per-ray jitter off (inference).  One "step" = one whole
+frame: get_rays (HIP) + ONE fused launch (sampler -> coarse density pass -> resampling -> fine pass
+-> compositing) over the 640,000 rays, inputs/outputs resident in HBM.  Rays shard across ranks with
+no data-path collective: every rank renders its own frames (weak scaling); value = all rays of all
+ranks / max-over-ranks wall time.
+
+The JSON line also carries
+  roofline     - the fused kernel against the dense 16-bit MFMA peak (2.5 PFLOP/s), from HIP-event
+                 timing of the launches inside the timed region; algorithmic FLOPs per ray =
+                 64 x 982,528 (density-only coarse pass) + 192 x 1,186,816 (full fine pass), Linear
+                 layers only, 2 FLOP per MAC; `traffic` = HBM bytes per launch from the committed
+                 rocprofv3 PMC pass (profiles/), or null;
+  cpu_baseline - the CPU oracle (PyTorch CPU ops, same operator sequence as the reference) timed on
+                 this box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H = W = 800
+FOCAL = 0.5 * W / math.tan(0.5 * 0.6911112)  # = 1111.11 (camera_angle_x of the Lego set, blender.py:250-252)
+NEAR, FAR = 2.0, 6.0
+S, NI = 64, 128
+FLOP_DENSITY = 982528
+FLOP_FULL = 1186816
+FLOP_PER_RAY = S * FLOP_DENSITY + (S + NI) * FLOP_FULL
+PEAK_TFLOPS = 2500.0  # dense bf16/fp16 MFMA, MI355X_MICROARCH.md
+
+
+def init_sd(seed):
+    """Reference-order default init (src/core/models.py:96-108) with torch only (no oracle import:
+    the product path must not depend on oracle/)."""
+    from fs_nerf_amd.core.models import NeRF
+    torch.manual_seed(seed)
+    m = NeRF(3, 3, 8, 256, (4,), pos_fn={"n_freqs": 10, "log_space": True},
+             dir_fn={"n_freqs": 4, "log_space": True})
+    with torch.no_grad():
+        m.sigma.weight.mul_(64.0)
+        m.sigma.bias.add_(1.0)
+    return m
+
+
+def orbit_pose(phi_deg):
+    th, ph = 50.0 / 180.0 * math.pi, phi_deg / 180.0 * math.pi
+    tr = torch.tensor([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 4.0311289], [0, 0, 0, 1.0]])
+    rt = torch.tensor([[1, 0, 0, 0], [0, math.cos(th), -math.sin(th), 0], [0, math.sin(th), math.cos(th), 0],
+                       [0, 0, 0, 1.0]])
+    rp = torch.tensor([[math.cos(ph), -math.sin(ph), 0, 0], [math.sin(ph), math.cos(ph), 0, 0], [0, 0, 1, 0],
+                       [0, 0, 0, 1.0]])
+    return rp @ (rt @ tr)
+
+
+def cpu_baseline(target_s=15.0):
+    """Oracle (kind 'port') on the host cores, bounded sample of the same workload."""
+    from oracle import fsnerf_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd_c = O.init_nerf_state_dict(8, 256, [4], 10, 4, seed=42)
+    sd_f = O.init_nerf_state_dict(8, 256, [4], 10, 4, seed=43)
+    for sd in (sd_c, sd_f):
+        sd["sigma.weight"] = sd["sigma.weight"] * 64.0
+        sd["sigma.bias"] = sd["sigma.bias"] + 1.0
+    cfg = dict(n_layers=8, skip=[4], n_freqs=10, n_freqs_dir=4, log_space=True)
+    o, d = O.get_rays(O.pose_from_spherical(4.0311289, 50.0, 0.0), (H, W, FOCAL))
+    o, d = o.reshape(-1, 3), d.reshape(-1, 3)
+
+    def run(n):
+        idx = torch.arange(0, H * W, (H * W) // n)[:n]
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            O.render_rays_oracle(o[idx].contiguous(), d[idx].contiguous(), sd_c, sd_f, cfg, near=NEAR, far=FAR,
+                                 n_samples=S, n_importance=NI, white_bkgd=True)
+        return time.perf_counter() - t0
+
+    run(256)  # warm-up
+    t_probe = run(512)
+    n = int(min(max(512, 512 * target_s / max(t_probe, 1e-3)), 65536))
+    t = run(n)
+    return {"value": n / t, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} rays of the 800x800 frame, 64+128 samples, two 8x256 nets, oracle/fsnerf_oracle.py "
+                      f"(PyTorch CPU fp32), {t:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--precision", default=os.environ.get("FSN_BENCH_PREC", "fp16x3"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    assert torch.cuda.is_available(), "bench.py needs the GPU (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from fs_nerf_amd import ops
+    from fs_nerf_amd.render import rendering as Rm
+    coarse, fine = init_sd(42), init_sd(43)
+    for m in (coarse, fine):
+        m.precision = args.precision
+        m.to(dev).eval()
+    est = Rm.StratifiedEstimator(NEAR, FAR, S, NI)
+    pc, pf = coarse.packed(), fine.packed()
+    torch.cuda.synchronize()
+
+    ev = []
+
+    def step(i, timed):
+        # ranks render different frames of the 90-frame orbit (blender.py:260-277)
+        pose = orbit_pose(((i * world + rank) % 90) * 4.0)
+        o, d = ops.get_rays(pose, H, W, FOCAL, dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rgb, op, depth, _ = ops.render_fused(pc, pf, o, d, near=NEAR, far=FAR, n_samples=S, n_importance=NI,
+                                             bkgd=(1.0, 1.0, 1.0), want_extras=False)
+        e1.record()
+        if timed:
+            ev.append((e0, e1))
+        return rgb, depth
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i, False)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i, True)
+    barrier()
+    dt = time.perf_counter() - t0
+    assert bool(torch.isfinite(out[0]).all())
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+
+    if rank == 0:
+        rays = world * args.steps * H * W
+        value = rays / dt
+        achieved = FLOP_PER_RAY * H * W / (kern_ms * 1e-3) / 1e12
+        traffic = None
+        pj = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if os.path.exists(pj):
+            try:
+                traffic = json.load(open(pj)).get("k_render_fused_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "rendered rays/sec (64+128 samples/ray, 8x256 MLP)", "value": value, "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+            "data": "synthetic",
+            "config": {"workload": "Lego-style orbit 800x800 (focal 1111.11, near 2, far 6), 64 coarse + 128 "
+                                   "importance samples (192 fine intervals), two 8x256 NeRF nets (seeds 42/43), "
+                                   "one fused launch per 640,000-ray frame incl. get_rays",
+                       "rays_per_step": H * W, "parallelism": f"rays x{world} (no data-path collective)"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_TFLOPS, "traffic": traffic,
+                         "kernel": "k_render_fused", "kernel_ms": kern_ms, "flop_per_ray": FLOP_PER_RAY},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

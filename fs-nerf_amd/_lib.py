@@ -12,6 +12,8 @@ LIB_PATH = os.path.join(CSRC, "libfsnerf_hip.so")
 
 FSN_PREC_BF16X3 = 0
 FSN_PREC_BF16 = 1
+FSN_PREC_FP16X3 = 2
+FSN_PREC_FP16 = 3
 
 
 class MlpDesc(C.Structure):

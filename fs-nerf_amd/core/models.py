@@ -38,10 +38,11 @@ class PositionalEncoder(nn.Module):
 
 
 class NeRF(nn.Module):
-    PRECISIONS = {"bf16x3": L.FSN_PREC_BF16X3, "bf16": L.FSN_PREC_BF16}
+    PRECISIONS = {"bf16x3": L.FSN_PREC_BF16X3, "bf16": L.FSN_PREC_BF16, "fp16x3": L.FSN_PREC_FP16X3,
+                  "fp16": L.FSN_PREC_FP16}
 
     def __init__(self, d_pos: int = 3, d_dir: int = 3, n_layers: int = 8, d_hidden: int = 256,
-                 skip: Tuple[int, ...] = (4,), precision: str = "bf16x3", **kwargs) -> None:
+                 skip: Tuple[int, ...] = (4,), precision: str = "fp16x3", **kwargs) -> None:
         super().__init__()
         if d_pos != 3 or d_dir != 3:
             raise ValueError("the HIP path is built for 3-D positions and directions")

@@ -45,8 +45,9 @@ FSN_HD void pack_piece(const PackArgs& a, int64_t piece, uint16_t out8[8]) {
     const int col = unit_src_col(Lg, ks, h, j);
     if (col < 0) continue;
     const float w = W[(int64_t)row * Lg.ld + col];
-    const uint16_t hi = bf16_rne(w);
-    out8[j] = part == 0 ? hi : bf16_rne(w - bf16_to_f32(hi));
+    const bool f16 = prec_is_f16(a.prec);
+    const uint16_t hi = half_rne(w, f16);
+    out8[j] = part == 0 ? hi : half_rne(w - half_to_f32(hi, f16), f16);
   }
 }
 
@@ -250,10 +251,15 @@ extern "C" int fsn_mlp_fwd(const fsn_mlp_desc* desc, int prec, const void* blob,
   if (cus <= 0) return FSN_E_HIP;
   MlpFwdArgs a{make_net_params(*desc, G, blob), x, dirs, pos_mask, dir_mask, n, out};
   hipStream_t s = as_stream(stream);
-  if (desc->d_hidden == 256) {
-    return prec == FSN_PREC_BF16X3 ? launch_mlp_fwd<8, FSN_PREC_BF16X3>(a, cus, s)
-                                   : launch_mlp_fwd<8, FSN_PREC_BF16>(a, cus, s);
+  const int key = (desc->d_hidden == 256 ? 4 : 0) + prec;
+  switch (key) {
+    case 0: return launch_mlp_fwd<4, 0>(a, cus, s);
+    case 1: return launch_mlp_fwd<4, 1>(a, cus, s);
+    case 2: return launch_mlp_fwd<4, 2>(a, cus, s);
+    case 3: return launch_mlp_fwd<4, 3>(a, cus, s);
+    case 4: return launch_mlp_fwd<8, 0>(a, cus, s);
+    case 5: return launch_mlp_fwd<8, 1>(a, cus, s);
+    case 6: return launch_mlp_fwd<8, 2>(a, cus, s);
+    default: return launch_mlp_fwd<8, 3>(a, cus, s);
   }
-  return prec == FSN_PREC_BF16X3 ? launch_mlp_fwd<4, FSN_PREC_BF16X3>(a, cus, s)
-                                 : launch_mlp_fwd<4, FSN_PREC_BF16>(a, cus, s);
 }

@@ -7,8 +7,9 @@
 //  * weights (A operands, pre-packed by mlp_layout.hpp) are streamed L2 -> LDS by
 //    global_load_lds_dwordx4 into a ring of 16-KiB phases shared by the 4 waves, LOOK phases
 //    ahead, with counted vmcnt + raw s_barrier (no full drain inside the stream);
-//  * FSN_PREC_BF16X3: a.w = ah.wh + al.wh + ah.wl (3 passes, fp32 accumulate) ~ fp32 accuracy;
-//    FSN_PREC_BF16: one pass.
+//  * x3 modes (FSN_PREC_FP16X3 default, FSN_PREC_BF16X3): a.w = ah.wh + al.wh + ah.wl, three MFMA
+//    passes on 16-bit high/low parts with fp32 accumulation (fp16x3 ~ fp32 accuracy, bf16x3
+//    ~1e-5 per product but no range limit); FSN_PREC_BF16 / FSN_PREC_FP16: one pass.
 //  * sigma (256 -> 1) and rgb (128 -> 3) heads are fp32 VALU dot products on the accumulators.
 #pragma once
 #include "common.hpp"
@@ -17,6 +18,8 @@
 namespace fsn {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(8))) short s16x8;  // 8 raw 16-bit elements (bf16 or fp16 bits)
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
@@ -27,7 +30,7 @@ constexpr int kRingBytes = kNSlot * kPhaseBytes;
 constexpr int kAuxCapFloats = 4096;  // LDS reserved per network for biases / heads
 
 struct Frag {  // one k-step (16 features x 32 samples) of activations as MFMA B operand
-  bf16x8 hi, lo;
+  s16x8 hi, lo;
 };
 
 // ---------------------------------------------------------------- weight stream
@@ -126,12 +129,25 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 // ---------------------------------------------------------------- helpers
-__device__ __forceinline__ void split_store(const float v[8], Frag& f, bool want_lo) {
+// float -> 16-bit element of the mode (round to nearest even) and back
+template <bool F16>
+__device__ __forceinline__ short to_h(float v) {
+  if (F16) { const _Float16 h = (_Float16)v; return __builtin_bit_cast(short, h); }
+  const __bf16 h = (__bf16)v;
+  return __builtin_bit_cast(short, h);
+}
+template <bool F16>
+__device__ __forceinline__ float from_h(short b) {
+  if (F16) return (float)__builtin_bit_cast(_Float16, b);
+  return (float)__builtin_bit_cast(__bf16, b);
+}
+template <bool F16, bool X3>
+__device__ __forceinline__ void split_store(const float v[8], Frag& f) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const __bf16 h = (__bf16)v[j];
+    const short h = to_h<F16>(v[j]);
     f.hi[j] = h;
-    f.lo[j] = want_lo ? (__bf16)(v[j] - (float)h) : (__bf16)0.0f;
+    f.lo[j] = X3 ? to_h<F16>(v[j] - from_h<F16>(h)) : (short)0;
   }
 }
 
@@ -181,9 +197,9 @@ __device__ __forceinline__ void sincos_f32(float a, float& s_out, float& c_out) 
 // Positional / direction encoding of one sample straight into B-operand fragments.
 // Slot layout = enc_slot_feature() in mlp_layout.hpp; value = reference feature (models.py:37-39)
 // times the frequency mask (LDS, all ones when absent).  NKS k-steps (NKS*8 slots per lane half).
-template <int NKS>
+template <int NKS, bool F16, bool X3>
 __device__ __forceinline__ void encode(float x0, float x1, float x2, int n_freqs, const float* __restrict__ freqs,
-                                       const float* __restrict__ mask, int h, bool want_lo, Frag (&out)[NKS]) {
+                                       const float* __restrict__ mask, int h, Frag (&out)[NKS]) {
   constexpr int SLOTS = 8 * NKS;
   constexpr int NPAIR = (SLOTS - 2) / 2;
   float v[SLOTS];
@@ -209,7 +225,7 @@ __device__ __forceinline__ void encode(float x0, float x1, float x2, int n_freqs
   v[SLOTS - 2] = ia;
   v[SLOTS - 1] = ib;
 #pragma unroll
-  for (int k = 0; k < NKS; ++k) split_store(&v[8 * k], out[k], want_lo);
+  for (int k = 0; k < NKS; ++k) split_store<F16, X3>(&v[8 * k], out[k]);
 }
 
 // ---------------------------------------------------------------- one GEMM layer
@@ -221,14 +237,21 @@ struct Heads {
 };
 
 // One unit: this wave's 32-sample slice of  acc[32 out x 32 samples] += W_unit[32 x 16] . act[16 x 32]
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma16(const s16x8& a, const s16x8& b, const f32x16& c) {
+  if (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 template <int PREC>
 __device__ __forceinline__ void unit_mfma(const char* ubase, const Frag& b, f32x16& acc) {
-  const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ubase);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.hi, acc, 0, 0, 0);
-  if (PREC == FSN_PREC_BF16X3) {
-    const bf16x8 al = *reinterpret_cast<const bf16x8*>(ubase + 1024);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b.hi, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b.lo, acc, 0, 0, 0);
+  constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
+  const s16x8 ah = *reinterpret_cast<const s16x8*>(ubase);
+  acc = mfma16<F16>(ah, b.hi, acc);
+  if (X3) {
+    const s16x8 al = *reinterpret_cast<const s16x8*>(ubase + 1024);
+    acc = mfma16<F16>(al, b.hi, acc);
+    acc = mfma16<F16>(ah, b.lo, acc);
   }
 }
 
@@ -241,11 +264,11 @@ __device__ __forceinline__ void unit_mfma(const char* ubase, const Frag& b, f32x
 template <int PREC, int NT_OUT, int KS_ACT, int KS_ENC, int EPI, int NACT, int NENC, int NOUT>
 __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int aux_bias, const Frag (&act)[NACT],
                                            const Frag (&enc)[NENC], Frag (&out)[NOUT], Heads& heads, int h) {
-  constexpr int UPP = (PREC == FSN_PREC_BF16X3) ? 8 : 16;
-  constexpr int UB = (PREC == FSN_PREC_BF16X3) ? 2048 : 1024;
+  constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
+  constexpr int UPP = X3 ? 8 : 16;
+  constexpr int UB = X3 ? 2048 : 1024;
   constexpr int KS = KS_ACT + KS_ENC;
   static_assert(KS_ACT <= NACT && KS_ENC <= NENC, "operand arrays too small");
-  constexpr bool want_lo = (PREC == FSN_PREC_BF16X3);
   const float* bias = net.aux + aux_bias;
 #pragma unroll
   for (int t = 0; t < NT_OUT; ++t) {
@@ -294,8 +317,8 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
       float v[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) v[i] = acc[i];
-      split_store(&v[0], out[(2 * t) < NOUT ? 2 * t : 0], want_lo);
-      split_store(&v[8], out[(2 * t + 1) < NOUT ? 2 * t + 1 : 0], want_lo);
+      split_store<F16, X3>(&v[0], out[(2 * t) < NOUT ? 2 * t : 0]);
+      split_store<F16, X3>(&v[8], out[(2 * t + 1) < NOUT ? 2 * t + 1 : 0]);
     }
   }
 }
@@ -307,13 +330,13 @@ template <int NT, int PREC, bool FULL>
 __device__ __forceinline__ void mlp_tile(WStream& st, const NetDev& net, float px, float py, float pz,
                                          float dx, float dy, float dz, float& sigma, float (&rgb)[3]) {
   constexpr int NA = 2 * NT;
-  constexpr bool want_lo = (PREC == FSN_PREC_BF16X3);
+  constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
   const int h = (threadIdx.x >> 5) & 1;
   constexpr int D = 32 * NT;
   const int L = net.n_layers;
   const float* misc = net.aux + (L + 5) * D;
   Frag pe[kKsPos];
-  encode<kKsPos>(px, py, pz, net.n_freqs_pos, misc + 4, net.pos_mask, h, want_lo, pe);
+  encode<kKsPos, F16, X3>(px, py, pz, net.n_freqs_pos, misc + 4, net.pos_mask, h, pe);
   Frag A[NA], B[NA];
   Frag none[1];
   Heads heads{0.f, {0.f, 0.f, 0.f}};
@@ -343,7 +366,7 @@ __device__ __forceinline__ void mlp_tile(WStream& st, const NetDev& net, float p
     // connection (no activation, models.py:130), then branch on [feat, dir_enc] (models.py:131-133)
     gemm_layer<PREC, NT, NA, 0, EPI_CVT>(st, net, L * D, B, pe, A, heads, h);
     Frag de[kKsDir];
-    encode<kKsDir>(dx, dy, dz, net.n_freqs_dir, misc + 20, net.dir_mask, h, want_lo, de);
+    encode<kKsDir, F16, X3>(dx, dy, dz, net.n_freqs_dir, misc + 20, net.dir_mask, h, de);
     gemm_layer<PREC, NT / 2, NA, kKsDir, EPI_RGB>(st, net, (L + 1) * D, A, de, B, heads, h);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {

@@ -9,7 +9,7 @@
 // exactly the B-operand layout of the next layer, so activations never leave registers.
 //
 // A "unit" is the A operand of one (layer, out-tile t, k-step ks): one 1-KiB fragment of the
-// bf16 high parts and (FSN_PREC_BF16X3) one 1-KiB fragment of the bf16 low parts, lane-linear
+// 16-bit (bf16 or fp16) high parts and, in the x3 modes, one 1-KiB fragment of the low parts, lane-linear
 // (lane l owns bytes [16 l, 16 l + 16)).  Units are stored in the order the kernel consumes
 // them (layer, then out-tile, then k-step) and streamed through LDS in 16-KiB "phases".
 #pragma once
@@ -31,7 +31,9 @@ constexpr int kKsPos = 4;  // k-steps (of 16) reserved for the positional encodi
 constexpr int kKsDir = 2;  // k-steps reserved for the direction encoding: 32 slots
 constexpr int kMaxLayers = 16;
 
-FSN_HD int unit_bytes(int prec) { return prec == FSN_PREC_BF16X3 ? 2048 : 1024; }
+FSN_HD bool prec_is_x3(int prec) { return (prec & 1) == 0; }
+FSN_HD bool prec_is_f16(int prec) { return prec >= 2; }
+FSN_HD int unit_bytes(int prec) { return prec_is_x3(prec) ? 2048 : 1024; }
 FSN_HD int units_per_phase(int prec) { return kPhaseBytes / unit_bytes(prec); }
 
 // One GEMM of the network as the kernel sees it.
@@ -103,10 +105,44 @@ FSN_HD float bf16_to_f32(uint16_t b) {
   return v.f;
 }
 
+// IEEE binary16, round to nearest even, subnormals kept
+FSN_HD uint16_t f16_rne(float f) {
+  union { float f; uint32_t u; } v;
+  v.f = f;
+  const uint32_t sign = (v.u >> 16) & 0x8000u;
+  uint32_t x = v.u & 0x7fffffffu;
+  if (x > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);
+  if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);  // >= 65520 rounds to infinity
+  if (x < 0x38800000u) {                                      // < 2^-14: subnormal half or zero
+    v.u = x;
+    const float a = v.f * 16777216.0f;  // * 2^24, exact
+    float r = (float)(int)a;            // a < 1024: truncate, then round half to even by hand
+    const float frac = a - r;
+    if (frac > 0.5f || (frac == 0.5f && ((int)r & 1))) r += 1.0f;
+    return (uint16_t)(sign | (uint32_t)(int)r);
+  }
+  x += 0xfffu + ((x >> 13) & 1u);
+  return (uint16_t)(sign | ((x - 0x38000000u) >> 13));
+}
+FSN_HD float f16_to_f32(uint16_t h) {
+  union { float f; uint32_t u; } v;
+  const uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+  const uint32_t e = (h >> 10) & 31u, m = h & 0x3ffu;
+  if (e == 0) {
+    v.f = (float)m * 5.9604644775390625e-08f;  // m * 2^-24
+    v.u |= sign;
+    return v.f;
+  }
+  v.u = sign | (e == 31 ? 0x7f800000u | (m << 13) : ((e + 112u) << 23) | (m << 13));
+  return v.f;
+}
+FSN_HD uint16_t half_rne(float f, bool f16) { return f16 ? f16_rne(f) : bf16_rne(f); }
+FSN_HD float half_to_f32(uint16_t h, bool f16) { return f16 ? f16_to_f32(h) : bf16_to_f32(h); }
+
 // Fills `G` from the descriptor; returns 0 or an FSN_E_* code (message via set_error on host).
 inline int build_geom(const fsn_mlp_desc& d, int prec, NetGeom& G, const char** why) {
   *why = "";
-  if (prec != FSN_PREC_BF16X3 && prec != FSN_PREC_BF16) { *why = "unknown precision mode"; return FSN_E_INVALID; }
+  if (prec < 0 || prec > 3) { *why = "unknown precision mode"; return FSN_E_INVALID; }
   if (d.d_hidden != 256 && d.d_hidden != 128) { *why = "d_hidden must be 128 or 256"; return FSN_E_UNSUPPORTED; }
   if (d.n_layers < 2 || d.n_layers > kMaxLayers) { *why = "n_layers must be in [2,16]"; return FSN_E_UNSUPPORTED; }
   if (d.n_freqs_pos < 0 || d.n_freqs_pos > 10) { *why = "n_freqs (position) must be <= 10"; return FSN_E_UNSUPPORTED; }

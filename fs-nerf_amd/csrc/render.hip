@@ -200,7 +200,15 @@ extern "C" int fsn_render_rays_fused(const fsn_mlp_desc* desc, int prec, const v
   const int cus = fsn_device_cus();
   if (cus <= 0) return FSN_E_HIP;
   hipStream_t s = as_stream(stream);
-  if (desc->d_hidden == 256)
-    return prec == FSN_PREC_BF16X3 ? launch_render<8, FSN_PREC_BF16X3>(k, cus, s) : launch_render<8, FSN_PREC_BF16>(k, cus, s);
-  return prec == FSN_PREC_BF16X3 ? launch_render<4, FSN_PREC_BF16X3>(k, cus, s) : launch_render<4, FSN_PREC_BF16>(k, cus, s);
+  const int key = (desc->d_hidden == 256 ? 4 : 0) + prec;
+  switch (key) {
+    case 0: return launch_render<4, 0>(k, cus, s);
+    case 1: return launch_render<4, 1>(k, cus, s);
+    case 2: return launch_render<4, 2>(k, cus, s);
+    case 3: return launch_render<4, 3>(k, cus, s);
+    case 4: return launch_render<8, 0>(k, cus, s);
+    case 5: return launch_render<8, 1>(k, cus, s);
+    case 6: return launch_render<8, 2>(k, cus, s);
+    default: return launch_render<8, 3>(k, cus, s);
+  }
 }
