@@ -52,7 +52,7 @@ def init_sd(seed):
              dir_fn={"n_freqs": 4, "log_space": True})
     with torch.no_grad():
         m.sigma.weight.mul_(64.0)
-        m.sigma.bias.add_(1.0)
+        m.sigma.bias.add_(3.0)
     return m
 
 
@@ -74,7 +74,7 @@ def cpu_baseline(target_s=15.0):
     sd_f = O.init_nerf_state_dict(8, 256, [4], 10, 4, seed=43)
     for sd in (sd_c, sd_f):
         sd["sigma.weight"] = sd["sigma.weight"] * 64.0
-        sd["sigma.bias"] = sd["sigma.bias"] + 1.0
+        sd["sigma.bias"] = sd["sigma.bias"] + 3.0
     cfg = dict(n_layers=8, skip=[4], n_freqs=10, n_freqs_dir=4, log_space=True)
     o, d = O.get_rays(O.pose_from_spherical(4.0311289, 50.0, 0.0), (H, W, FOCAL))
     o, d = o.reshape(-1, 3), d.reshape(-1, 3)

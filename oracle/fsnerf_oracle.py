@@ -306,7 +306,8 @@ def render_rays_oracle(rays_o: Tensor, rays_d: Tensor, sd_coarse: Dict[str, Tens
                        sd_fine: Optional[Dict[str, Tensor]], cfg: dict, *, near: float, far: float,
                        n_samples: int, n_importance: int = 0, u: Optional[Tensor] = None,
                        u_fine: Optional[Tensor] = None, white_bkgd: bool = False,
-                       pos_mask: Optional[Tensor] = None, dir_mask: Optional[Tensor] = None):
+                       pos_mask: Optional[Tensor] = None, dir_mask: Optional[Tensor] = None,
+                       edges_override: Optional[Tensor] = None):
     """The whole path in the reference's operator order (`src/render/rendering.py:58-107`):
       1. intervals from `stratified_edges` (fills the `estimator.sampling` slot, `:66-74`);
       2. density-only pass sigma_fn: x = o + d*(t0+t1)/2; sigma = model(x)       (`:58-64`)
@@ -317,7 +318,10 @@ def render_rays_oracle(rays_o: Tensor, rays_d: Tensor, sd_coarse: Dict[str, Tens
       5. t_vals = (t0+t1)/2 (`:105`).
     `sd_fine is None` uses one network for both passes, as the reference does.
     Returns ((rgb [R,3], opacity [R,1], depth [R,1], extras), ray_indices [N], t_vals [N]);
-    extras additionally holds "edges" [R,S'+1] and, when hierarchical, "weights_coarse" [R,S]."""
+    extras additionally holds "edges" [R,S'+1] and, when hierarchical, "weights_coarse" [R,S].
+    `edges_override` [R,S'+1] replaces the result of steps 1-3 for step 4 (tests use it to check the
+    full pass + integration on exactly the sample set another implementation produced, because
+    inverse-CDF resampling is ill-conditioned where the coarse pdf is ~0)."""
     R = rays_o.shape[0]
     dt = rays_o.dtype
     mk = dict(n_layers=cfg["n_layers"], skip=cfg["skip"], n_freqs=cfg["n_freqs"],
@@ -332,6 +336,8 @@ def render_rays_oracle(rays_o: Tensor, rays_d: Tensor, sd_coarse: Dict[str, Tens
         sdt = sig * (t1 - t0)
         w_coarse = torch.exp(-(torch.cumsum(sdt, -1) - sdt)) * (1.0 - torch.exp(-sdt))
         edges = merge_edges(edges, sample_pdf(edges, w_coarse, n_importance, u_fine))
+    if edges_override is not None:
+        edges = edges_override.to(dt)
     sd = sd_fine if sd_fine is not None else sd_coarse
     t0, t1 = edges[:, :-1], edges[:, 1:]
     S = t0.shape[1]

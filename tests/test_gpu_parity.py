@@ -44,7 +44,7 @@ def load_sd(golden_dir, tag, sigma64=True):
     sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
     if sigma64:
         sd["sigma.weight"] = sd["sigma.weight"] * 64.0
-        sd["sigma.bias"] = sd["sigma.bias"] + 1.0
+        sd["sigma.bias"] = sd["sigma.bias"] + 3.0
     return g, sd
 
 
@@ -288,40 +288,24 @@ def _rays(R, seed, hw=100, focal=138.88887889922103):
     return o.reshape(-1, 3)[idx].contiguous(), d.reshape(-1, 3)[idx].contiguous(), gen
 
 
-def _check_render(out, want, what, hier=False):
+def _check_render(out, want, what):
+    """Per-sample and per-ray outputs; `want` was computed on the same sample set (same edges)."""
     (rgb, op, dep, ex), ri, tv = out
     (wrgb, wop, wdep, wex), wri, wtv = want
-    R = wrgb.shape[0]
-    e, we = ex["edges"].cpu(), wex["edges"]
-    e_ok = (e - we).abs() <= 1e-5 + 1e-5 * we.abs()
-    if hier:
-        # Inverse-CDF resampling is ill-conditioned where the coarse pdf is ~0 (dt/du = bin width / pdf
-        # ~ 4e3 for an empty bin), so last-bit differences in the coarse weights move a few importance
-        # samples inside empty space.  Both sample sets are valid; per-sample quantities are compared on
-        # the rays whose sample sets agree, per-ray outputs on all rays.
-        assert e_ok.float().mean().item() > 0.995, f"{what}: {int((~e_ok).sum())} of {e_ok.numel()} edges differ"
-        rays_ok = e_ok.all(-1)
-        assert rays_ok.float().mean().item() > 0.7
-    else:
-        assert bool(e_ok.all()), f"{what}: edges differ"
-        rays_ok = torch.ones(R, dtype=torch.bool)
+    close(ex["edges"], wex["edges"], rtol=0, atol=0, what=what + " edges")
     # the test nets emit raw sigma of both signs (models.py:127), so T can exceed 1: scale the absolute
     # floor by the largest weight
     wmax = max(float(wex["weights"].abs().max()), 1.0)
-    w = ex["weights"].reshape(wex["weights"].shape).cpu()
-    close(w[rays_ok], wex["weights"][rays_ok], atol=1e-5 * wmax, what=what + " weights")
-    close(rgb.cpu()[rays_ok], wrgb[rays_ok], atol=1e-5 * wmax, what=what + " rgb_map")
-    close(op.cpu()[rays_ok], wop[rays_ok], atol=1e-5 * wmax, what=what + " opacity")
-    if hier and not bool(rays_ok.all()):
-        close(rgb.cpu()[~rays_ok], wrgb[~rays_ok], rtol=1e-3, atol=1e-3 * wmax, what=what + " rgb_map (moved samples)")
-    # depth = sum(w t)/max(sum w, eps): compare where it is well conditioned (sum|w| / |sum w| small)
+    close(ex["weights"].reshape(wex["weights"].shape), wex["weights"], atol=1e-5 * wmax, what=what + " weights")
+    close(rgb, wrgb, atol=1e-5 * wmax, what=what + " rgb_map")
+    close(op, wop, atol=1e-5 * wmax, what=what + " opacity")
+    # depth = sum(w t)/max(sum w, eps): compare where it is well conditioned
     cond = wex["weights"].abs().sum(-1, keepdim=True) / wop.abs().clamp(min=1e-12)
-    dep_ok = (cond.squeeze(-1) < 50.0) & rays_ok
+    dep_ok = ((cond < 50.0) & (wop > 1e-3)).squeeze(-1)
     assert dep_ok.float().mean().item() > 0.5
     close(dep.cpu()[dep_ok], wdep[dep_ok], atol=(1e-4 * cond[dep_ok].clamp(min=1.0)).numpy(), what=what + " depth_map")
     assert torch.equal(ri.cpu(), wri)
-    close(tv.cpu()[rays_ok.repeat_interleave(we.shape[1] - 1)], wtv[rays_ok.repeat_interleave(we.shape[1] - 1)],
-          rtol=1e-5, atol=1e-5, what=what + " t_vals")
+    close(tv, wtv, rtol=0, atol=0, what=what + " t_vals")
 
 
 @pytest.mark.parametrize("tag,R,S,white,jit", [("4x128", 4096, 64, False, "ray"), ("4x128", 100, 64, True, "none"),
@@ -334,9 +318,12 @@ def test_render_rays_coarse_only(dev, golden_dir, tag, R, S, white, jit):
     u = None if jit == "none" else (torch.rand(R, generator=gen) if jit == "ray" else torch.rand(R, S + 1, generator=gen))
     # float32 oracle = "the reference PyTorch CPU path": sample positions o + d*(t0+t1)/2 are formed in
     # float32 by both sides with the same op sequence (their low bits matter: the encoder multiplies by 2^9)
-    want = O.render_rays_oracle(o, d, sd, None, CFG[tag], near=2.0, far=6.0, n_samples=S, u=u, white_bkgd=white)
     est = Rm.StratifiedEstimator(2.0, 6.0, S, 0)
     out = Rm.render_rays(o, d, est, m, train=False, white_bkgd=white, device=dev, u=None if u is None else u.to(dev))
+    want = O.render_rays_oracle(o, d, sd, None, CFG[tag], near=2.0, far=6.0, n_samples=S, u=u, white_bkgd=white)
+    close(out[0][3]["edges"], want[0][3]["edges"], rtol=0, atol=5e-7, what="stratified edges")  # <= 1 ulp
+    want = O.render_rays_oracle(o, d, sd, None, CFG[tag], near=2.0, far=6.0, n_samples=S, u=u, white_bkgd=white,
+                                edges_override=out[0][3]["edges"].cpu())
     _check_render(out, want, f"{tag} S={S}")
     assert out[0][3]["sigmas"].shape == (R * S,) and out[0][3]["rgbs"].shape == (R * S, 3)
 
@@ -350,7 +337,7 @@ def test_render_rays_hierarchical(dev, golden_dir, tag, R, S, NI, two_nets):
     if two_nets:
         sd_f = O.init_nerf_state_dict(DIMS[tag][0], DIMS[tag][1], [4], 10, 4, seed=43)
         sd_f["sigma.weight"] = sd_f["sigma.weight"] * 64.0
-        sd_f["sigma.bias"] = sd_f["sigma.bias"] + 1.0
+        sd_f["sigma.bias"] = sd_f["sigma.bias"] + 3.0
     mc = make_model(sd, *DIMS[tag], [4], dev)
     mf = make_model(sd_f, *DIMS[tag], [4], dev) if two_nets else None
     o, d, gen = _rays(R, 7)
@@ -361,9 +348,20 @@ def test_render_rays_hierarchical(dev, golden_dir, tag, R, S, NI, two_nets):
     est = Rm.StratifiedEstimator(2.0, 6.0, S, NI)
     out = Rm.render_rays(o, d, est, mc, train=False, white_bkgd=True, device=dev, model_fine=mf, u=u.to(dev),
                          u_fine=uf.to(dev))
+    # stage 1 (coarse density pass -> weights -> resampling): weights strictly; the resampled edges up to
+    # the ill-conditioning of the inverse CDF (dt/du = bin width / pdf ~ 4e3 where the coarse pdf is ~0,
+    # so last-bit differences of the weights move a few importance samples inside empty space)
     wc = want[0][3]["weights_coarse"]
     close(out[0][3]["weights_coarse"], wc, atol=1e-5 * max(float(wc.abs().max()), 1.0), what="coarse weights")
-    _check_render(out, want, f"{tag} {S}+{NI}", hier=True)
+    e, we = out[0][3]["edges"].cpu(), want[0][3]["edges"]
+    assert bool((e[:, 1:] >= e[:, :-1]).all())
+    moved = (e - we).abs() > 1e-4
+    assert moved.float().mean().item() < 5e-3, f"{int(moved.sum())} of {moved.numel()} edges moved"
+    close(out[0][0], want[0][0], rtol=2e-3, atol=2e-3, what="rgb_map, own sample sets")
+    # stage 2 (fine pass + integration) strictly, on exactly the sample set the kernel produced
+    want2 = O.render_rays_oracle(o, d, sd, sd_f, CFG[tag], near=2.0, far=6.0, n_samples=S, n_importance=NI, u=u,
+                                 u_fine=uf, white_bkgd=True, edges_override=e)
+    _check_render(out, want2, f"{tag} {S}+{NI}")
 
 
 def test_render_rays_generic_model_matches_fused(dev, golden_dir):
