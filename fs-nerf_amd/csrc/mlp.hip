@@ -145,12 +145,20 @@ struct MlpFwdArgs {
   float* out;
 };
 
+// sample source of the standalone kernel: the tile's positions / directions staged in LDS
+struct TileSrc {
+  const float* p;  // this lane's [x,y,z,dx,dy,dz] in LDS
+  __device__ __forceinline__ void pos(float& x, float& y, float& z) const { x = p[0]; y = p[1]; z = p[2]; }
+  __device__ __forceinline__ void dir(float& x, float& y, float& z) const { x = p[3]; y = p[4]; z = p[5]; }
+};
+
 // Persistent workgroups; tile = 128 consecutive samples; wave w / lane (r,h) owns sample
-// 128*tile + 32*w + r.  LDS: [weight ring 64 KiB][aux + masks].
+// 128*tile + 32*w + r.  LDS: [weight ring 64 KiB][aux + masks][tile inputs 128 x 6 floats].
 template <int NT, int PREC, bool FULL>
 __global__ __launch_bounds__(256) void k_mlp_fwd(MlpFwdArgs a) {
-  __shared__ __attribute__((aligned(1024))) char smem[kRingBytes + (kAuxCapFloats + 96) * 4];
+  __shared__ __attribute__((aligned(1024))) char smem[kRingBytes + (kAuxCapFloats + 96) * 4 + 128 * 6 * 4];
   float* aux_lds = reinterpret_cast<float*>(smem + kRingBytes);
+  float* in_lds = aux_lds + kAuxCapFloats + 96;
   NetDev net;
   load_net(a.net, a.pos_mask, a.dir_mask, aux_lds, net);
   __syncthreads();
@@ -163,11 +171,15 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(MlpFwdArgs a) {
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t s = tile * 128 + wave * 32 + (lane & 31);
     const int64_t sc = s < a.n ? s : a.n - 1;
-    const float px = a.x[3 * sc], py = a.x[3 * sc + 1], pz = a.x[3 * sc + 2];
-    float dx = 0.f, dy = 0.f, dz = 0.f;
-    if (full) { dx = a.dirs[3 * sc]; dy = a.dirs[3 * sc + 1]; dz = a.dirs[3 * sc + 2]; }
+    if (lane < 32) {  // each wave stages (and later reads) only its own 32 samples: no workgroup barrier
+      float* q = in_lds + (wave * 32 + lane) * 6;
+      q[0] = a.x[3 * sc]; q[1] = a.x[3 * sc + 1]; q[2] = a.x[3 * sc + 2];
+      if (full) { q[3] = a.dirs[3 * sc]; q[4] = a.dirs[3 * sc + 1]; q[5] = a.dirs[3 * sc + 2]; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const TileSrc src{in_lds + (wave * 32 + (lane & 31)) * 6};
     float sigma, rgb[3] = {0.f, 0.f, 0.f};
-    mlp_tile<NT, PREC, FULL>(st, net, px, py, pz, dx, dy, dz, sigma, rgb);
+    mlp_tile<NT, PREC, FULL>(st, net, src, sigma, rgb);
     if (lane < 32 && s < a.n) {
       if (full) {
         f32x4 o = {rgb[0], rgb[1], rgb[2], sigma};

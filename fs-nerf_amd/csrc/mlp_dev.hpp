@@ -324,48 +324,61 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
 }
 
 // ---------------------------------------------------------------- whole network, one tile
-// Inputs: this lane's sample position (and direction when `full`); lanes l and l+32 hold the
-// same sample.  Outputs (valid in all lanes): sigma, and rgb when FULL.
-template <int NT, int PREC, bool FULL>
-__device__ __forceinline__ void mlp_tile(WStream& st, const NetDev& net, float px, float py, float pz,
-                                         float dx, float dy, float dz, float& sigma, float (&rgb)[3]) {
+// `src` supplies this lane's sample on demand: src.pos(x,y,z) and src.dir(x,y,z) (lanes l and l+32
+// hold the same sample).  The position is re-read and re-encoded at every wide (skip) layer
+// instead of keeping its 32 operand registers alive across the hidden layers, and the direction
+// is read only in front of the branch layer: the register file (512 per lane) is the scarce
+// resource of this kernel.  Outputs (valid in all lanes): sigma, and rgb when FULL.
+template <int NT, int PREC, bool FULL, class Src>
+__device__ __forceinline__ void mlp_tile(WStream& st, const NetDev& net, const Src& src, float& sigma,
+                                         float (&rgb)[3]) {
   constexpr int NA = 2 * NT;
   constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
   const int h = (threadIdx.x >> 5) & 1;
   constexpr int D = 32 * NT;
   const int L = net.n_layers;
   const float* misc = net.aux + (L + 5) * D;
-  Frag pe[kKsPos];
-  encode<kKsPos, F16, X3>(px, py, pz, net.n_freqs_pos, misc + 4, net.pos_mask, h, pe);
   Frag A[NA], B[NA];
   Frag none[1];
   Heads heads{0.f, {0.f, 0.f, 0.f}};
-  gemm_layer<PREC, NT, 0, kKsPos, EPI_RELU_CVT>(st, net, 0, none, pe, A, heads, h);
+  {
+    Frag pe[kKsPos];
+    float px, py, pz;
+    src.pos(px, py, pz);
+    encode<kKsPos, F16, X3>(px, py, pz, net.n_freqs_pos, misc + 4, net.pos_mask, h, pe);
+    gemm_layer<PREC, NT, 0, kKsPos, EPI_RELU_CVT>(st, net, 0, none, pe, A, heads, h);
+  }
+#define FSN_HIDDEN(EPI, IN, OUT, LIDX)                                                                     \
+  do {                                                                                                     \
+    if ((net.skip_mask >> ((LIDX)-1)) & 1u) {                                                              \
+      Frag pe[kKsPos];                                                                                     \
+      float px, py, pz;                                                                                    \
+      src.pos(px, py, pz);                                                                                 \
+      encode<kKsPos, F16, X3>(px, py, pz, net.n_freqs_pos, misc + 4, net.pos_mask, h, pe);                 \
+      gemm_layer<PREC, NT, NA, kKsPos, EPI>(st, net, (LIDX)*D, IN, pe, OUT, heads, h);                     \
+    } else {                                                                                               \
+      gemm_layer<PREC, NT, NA, 0, EPI>(st, net, (LIDX)*D, IN, none, OUT, heads, h);                        \
+    }                                                                                                      \
+  } while (0)
   for (int l = 1; l <= L - 2; l += 2) {
-    if ((net.skip_mask >> (l - 1)) & 1u)
-      gemm_layer<PREC, NT, NA, kKsPos, EPI_RELU_CVT>(st, net, l * D, A, pe, B, heads, h);
-    else
-      gemm_layer<PREC, NT, NA, 0, EPI_RELU_CVT>(st, net, l * D, A, pe, B, heads, h);
+    FSN_HIDDEN(EPI_RELU_CVT, A, B, l);
     if (l + 1 <= L - 2) {
-      if ((net.skip_mask >> l) & 1u)
-        gemm_layer<PREC, NT, NA, kKsPos, EPI_RELU_CVT>(st, net, (l + 1) * D, B, pe, A, heads, h);
-      else
-        gemm_layer<PREC, NT, NA, 0, EPI_RELU_CVT>(st, net, (l + 1) * D, B, pe, A, heads, h);
+      FSN_HIDDEN(EPI_RELU_CVT, B, A, l + 1);
     } else {
 #pragma unroll
       for (int i = 0; i < NA; ++i) A[i] = B[i];
     }
   }
   // last hidden layer (index L-1): sigma head on its fp32 output (models.py:127,141)
-  if ((net.skip_mask >> (L - 2)) & 1u)
-    gemm_layer<PREC, NT, NA, kKsPos, (FULL ? EPI_LAST_FULL : EPI_LAST_DENS)>(st, net, (L - 1) * D, A, pe, B, heads, h);
-  else
-    gemm_layer<PREC, NT, NA, 0, (FULL ? EPI_LAST_FULL : EPI_LAST_DENS)>(st, net, (L - 1) * D, A, pe, B, heads, h);
+  FSN_HIDDEN((FULL ? EPI_LAST_FULL : EPI_LAST_DENS), A, B, L - 1);
+#undef FSN_HIDDEN
   sigma = heads.sigma + __shfl_xor(heads.sigma, 32, 64) + misc[0];
   if (FULL) {
     // connection (no activation, models.py:130), then branch on [feat, dir_enc] (models.py:131-133)
-    gemm_layer<PREC, NT, NA, 0, EPI_CVT>(st, net, L * D, B, pe, A, heads, h);
+    gemm_layer<PREC, NT, NA, 0, EPI_CVT>(st, net, L * D, B, none, A, heads, h);
     Frag de[kKsDir];
+    float dx, dy, dz;
+    src.dir(dx, dy, dz);
     encode<kKsDir, F16, X3>(dx, dy, dz, net.n_freqs_dir, misc + 20, net.dir_mask, h, de);
     gemm_layer<PREC, NT / 2, NA, kKsDir, EPI_RGB>(st, net, (L + 1) * D, A, de, B, heads, h);
 #pragma unroll

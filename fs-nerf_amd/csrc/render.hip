@@ -39,6 +39,20 @@ constexpr int kNetLdsBytes = (kAuxCapFloats + 96) * 4;
 constexpr int kRenderLdsBytes = kRingBytes + 2 * kNetLdsBytes + (int)sizeof(RenderLds);
 static_assert(kRenderLdsBytes <= 160 * 1024, "LDS budget");
 
+// sample source of the fused kernel: interval midpoint on the ray, x = o + d*(t0+t1)/2
+// (rendering.py:61,79), rebuilt from LDS whenever the MLP asks for it
+struct RaySrc {
+  const float* ray;  // [ox,oy,oz,dx,dy,dz] in LDS
+  const float* e;    // &edges[i] of this sample's interval in LDS
+  __device__ __forceinline__ void pos(float& x, float& y, float& z) const {
+    const float tm = e[0] + e[1];
+    x = ray[0] + ray[3] * tm / 2.0f;
+    y = ray[1] + ray[4] * tm / 2.0f;
+    z = ray[2] + ray[5] * tm / 2.0f;
+  }
+  __device__ __forceinline__ void dir(float& x, float& y, float& z) const { x = ray[3]; y = ray[4]; z = ray[5]; }
+};
+
 template <int NT, int PREC>
 __global__ __launch_bounds__(256) void k_render_fused(RenderKArgs k) {
   __shared__ __attribute__((aligned(1024))) char smem[kRenderLdsBytes];
@@ -80,12 +94,9 @@ __global__ __launch_bounds__(256) void k_render_fused(RenderKArgs k) {
         const int idx = sub * 128 + wave * 32 + (lane & 31);
         const int idc = min(idx, G * S - 1);
         const int g = idc / S, i = idc - g * S;
-        const float t0 = S_.edgesC[g * (S + 1) + i], t1 = S_.edgesC[g * (S + 1) + i + 1];
-        const float* ry = S_.rays + 6 * g;
-        const float tm = t0 + t1;
-        const float px = ry[0] + ry[3] * tm / 2.0f, py = ry[1] + ry[4] * tm / 2.0f, pz = ry[2] + ry[5] * tm / 2.0f;
+        const RaySrc src{S_.rays + 6 * g, S_.edgesC + g * (S + 1) + i};
         float sigma, rgb[3];
-        mlp_tile<NT, PREC, false>(st, netC, px, py, pz, 0.f, 0.f, 0.f, sigma, rgb);
+        mlp_tile<NT, PREC, false>(st, netC, src, sigma, rgb);
         if (lane < 32 && idx < G * S) S_.sigC[idx] = sigma;
       }
       lds_barrier();
@@ -108,12 +119,9 @@ __global__ __launch_bounds__(256) void k_render_fused(RenderKArgs k) {
       const int idx = sub * 128 + wave * 32 + (lane & 31);
       const int idc = min(idx, G * So - 1);
       const int g = idc / So, i = idc - g * So;
-      const float t0 = edges[g * (So + 1) + i], t1 = edges[g * (So + 1) + i + 1];
-      const float* ry = S_.rays + 6 * g;
-      const float tm = t0 + t1;
-      const float px = ry[0] + ry[3] * tm / 2.0f, py = ry[1] + ry[4] * tm / 2.0f, pz = ry[2] + ry[5] * tm / 2.0f;
+      const RaySrc src{S_.rays + 6 * g, edges + g * (So + 1) + i};
       float sigma, rgb[3];
-      mlp_tile<NT, PREC, true>(st, netF, px, py, pz, ry[3], ry[4], ry[5], sigma, rgb);
+      mlp_tile<NT, PREC, true>(st, netF, src, sigma, rgb);
       if (lane < 32 && idx < G * So) {
         S_.sigF[idx] = sigma;
         S_.rgbF[3 * idx + 0] = rgb[0];
