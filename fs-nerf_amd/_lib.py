@@ -8,7 +8,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libfsnerf_hip.so")
+LIB_PATH = os.environ.get("FSN_LIB_PATH", os.path.join(CSRC, "libfsnerf_hip.so"))  # override: A/B builds
 
 FSN_PREC_BF16X3 = 0
 FSN_PREC_BF16 = 1

@@ -24,7 +24,16 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 constexpr int kNSlot = 4;            // LDS ring slots (phases)
-constexpr int kLook = kNSlot - 1;    // phases staged ahead of the one being computed
+#ifndef FSN_LEAD
+#define FSN_LEAD 2
+#endif
+// A phase is "opened" (its loads waited for, workgroup barrier, next stage issued) kLead units
+// before the previous phase's last unit, so that the first LDS reads of the new phase are issued
+// underneath the tail MFMAs of the old one instead of behind the barrier.
+constexpr int kLead = FSN_LEAD;
+// phases staged ahead of the one being opened; with kLead > 0 the phase before the opened one is
+// still being read, so one more slot must stay untouched
+constexpr int kLook = kLead > 0 ? kNSlot - 2 : kNSlot - 1;
 constexpr int kGldsPerWave = kPhaseBytes / 1024 / 4;  // 1-KiB glds instructions per wave per phase
 constexpr int kRingBytes = kNSlot * kPhaseBytes;
 constexpr int kAuxCapFloats = 4096;  // LDS reserved per network for biases / heads
@@ -47,6 +56,7 @@ struct WStream {
   // consumer state
   uint32_t c_slot;
   const char* c_base;  // LDS address of the phase being computed (+ lane*16)
+  const char* n_base;  // ... of the phase opened last
 
   __device__ __forceinline__ void begin_pass_(uint32_t which) {
     s_which = which;
@@ -104,19 +114,29 @@ struct WStream {
     ptrB = pB; nphB = nB; repB = nB ? rB : 0;
     s_rep = 0; s_slot = 0; c_slot = 0;
     begin_pass_(repA ? 0u : 1u);
-    c_base = ring;
+    c_base = n_base = ring + (threadIdx.x & 63) * 16;
 #pragma unroll
     for (int i = 0; i < kLook; ++i) stage();
+    if (kLead > 0) open_next();  // every pass finds its first phase already opened
   }
-  // phase boundary: the next phase to compute has landed for every wave; everyone is done with the
-  // previous one, whose slot is restaged.  vmcnt counts in issue order, so allowing the
-  // (kLook-1)*kGldsPerWave youngest loads to stay in flight retires exactly the oldest phase.
-  __device__ __forceinline__ void boundary() {
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((kLook - 1) * kGldsPerWave) : "memory");
+  // Open the next phase: its loads have landed for every wave (vmcnt counts in issue order, so
+  // allowing the (kLook-1)*kGldsPerWave youngest loads to stay in flight retires exactly the oldest
+  // staged phase), every wave is past the phase whose slot is restaged next.
+  __device__ __forceinline__ void open_next() {
+#ifdef FSN_ABL_NOSTREAM  // timing experiment: no waits, barriers or staging
+    n_base = ring + c_slot * kPhaseBytes + (threadIdx.x & 63) * 16;
+    c_slot = (c_slot + 1) & (kNSlot - 1);
+    return;
+#endif
+    if (kLead > 0)
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((kLook - 1) * kGldsPerWave) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((kLook - 1) * kGldsPerWave) : "memory");
     stage();
-    c_base = ring + c_slot * kPhaseBytes + (threadIdx.x & 63) * 16;
+    n_base = ring + c_slot * kPhaseBytes + (threadIdx.x & 63) * 16;
     c_slot = (c_slot + 1) & (kNSlot - 1);
   }
+  __device__ __forceinline__ void enter_phase() { c_base = n_base; }
   // before the workgroup exits (or touches the ring for anything else)
   __device__ __forceinline__ void drain() {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -246,6 +266,14 @@ __device__ __forceinline__ f32x16 mfma16(const s16x8& a, const s16x8& b, const f
 template <int PREC>
 __device__ __forceinline__ void unit_mfma(const char* ubase, const Frag& b, f32x16& acc) {
   constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
+#ifdef FSN_ABL_NOLDS  // timing experiment: operands from registers instead of the LDS ring
+  acc = mfma16<F16>(b.lo, b.hi, acc);
+  if (X3) {
+    acc = mfma16<F16>(b.hi, b.hi, acc);
+    acc = mfma16<F16>(b.lo, b.lo, acc);
+  }
+  return;
+#endif
   const s16x8 ah = *reinterpret_cast<const s16x8*>(ubase);
   acc = mfma16<F16>(ah, b.hi, acc);
   if (X3) {
@@ -282,7 +310,12 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
     for (int ks = 0; ks < KS; ++ks) {
       constexpr int dummy = 0; (void)dummy;
       const int u = t * KS + ks;  // compile-time after unrolling
-      if (u % UPP == 0) st.boundary();
+      constexpr int TOTAL = NT_OUT * KS;
+      // open the phase that starts kLead units from here (the one after this layer's last unit too)
+      if (((u + kLead) % UPP == 0 && u + kLead <= TOTAL && (kLead > 0 || u < TOTAL)) ||
+          (kLead > 0 && u + kLead == TOTAL && TOTAL % UPP != 0))
+        st.open_next();
+      if (u % UPP == 0) st.enter_phase();
       const char* ub = st.c_base + (u % UPP) * UB;
       if (ks < KS_ACT) unit_mfma<PREC>(ub, act[ks < KS_ACT ? ks : 0], acc);
       else unit_mfma<PREC>(ub, enc[ks >= KS_ACT ? ks - KS_ACT : 0], acc);
@@ -313,7 +346,16 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
         }
       }
     }
+#ifdef FSN_ABL_NOCVT  // timing experiment: skip the fp32 -> hi/lo split of the layer output
     if (EPI == EPI_RELU_CVT || EPI == EPI_CVT || EPI == EPI_LAST_FULL) {
+      asm volatile("" ::"v"(acc));
+      out[(2 * t) < NOUT ? 2 * t : 0] = act[0];
+      out[(2 * t + 1) < NOUT ? 2 * t + 1 : 0] = act[0];
+    }
+    if (false) {
+#else
+    if (EPI == EPI_RELU_CVT || EPI == EPI_CVT || EPI == EPI_LAST_FULL) {
+#endif
       float v[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) v[i] = acc[i];
