@@ -1,0 +1,46 @@
+"""Ray sharding across the GPUs of one node (one process per GPU, torch.distributed).
+
+Rays are independent, so the rendering path partitions with NO data-path collective
+(SURVEY.md 8e): a rank renders its own frames (bench.py, weak scaling) or its own row block of a
+frame (`shard_rows`, then `fsn_get_rays(row0, nrows)` + the fused launch).  The only collectives
+are outside the timed path: `gather_rows` to assemble one image, `max_over_ranks` for timing.
+The backend is whatever the process group was created with ("nccl" = RCCL on the GPU box,
+"gloo" in the CPU tests)."""
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_rows(H: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous row block [row0, row0+nrows) of rank `rank`; the first H % world ranks get one more."""
+    base, rem = divmod(H, world)
+    nrows = base + (1 if rank < rem else 0)
+    row0 = rank * base + min(rank, rem)
+    return row0, nrows
+
+
+def shard_frames(n_frames: int, rank: int, world: int) -> range:
+    """Round-robin frame assignment (rank, rank+world, ...)."""
+    return range(rank, n_frames, world)
+
+
+def max_over_ranks(value: float, device) -> float:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_rows(local: torch.Tensor, H: int) -> torch.Tensor:
+    """All-gather row blocks [nrows_r, W, C] produced under `shard_rows` into the [H, W, C] image."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    max_rows = (H + world - 1) // world
+    pad = torch.zeros((max_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    return torch.cat([parts[r][: shard_rows(H, r, world)[1]] for r in range(world)], dim=0)

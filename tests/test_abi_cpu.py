@@ -1,0 +1,61 @@
+"""CPU: the C-ABI library loads and exports every symbol declared in include/fsnerf_hip.h; argument
+validation works without a GPU (no compute call is made); the host layer refuses CPU tensors."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+import fs_nerf_amd  # noqa: F401
+from fs_nerf_amd import _lib as L
+from fs_nerf_amd import ops
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    hdr = open(os.path.join(ROOT, "include", "fsnerf_hip.h")).read()
+    declared = set(re.findall(r"\b(fsn_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"fsn_stream_t"}
+    assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
+    lib = L.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.fsn_version() >= 100
+
+
+def test_argument_validation_without_gpu():
+    lib = L.lib()
+    assert lib.fsn_get_rays(None, 4, 4, 2.0, 0, 4, None, None, None) == -1
+    assert b"null" in lib.fsn_last_error()
+    pose = (C.c_float * 12)()
+    assert lib.fsn_get_rays(pose, 4, 4, 2.0, 3, 4, 1, 1, None) == -1          # rows out of range
+    assert lib.fsn_stratified_edges(2.0, 6.0, 0, 10, None, 0, None, None) == -1  # S = 0
+    assert lib.fsn_composite_fwd(None, None, None, None, 0, 64, None, None, None, None, None, None, None, None) == 0
+    desc = ops.make_desc(8, 256, [4], [1.0] * 10, [1.0] * 4)
+    assert lib.fsn_mlp_blob_bytes(C.byref(desc), 0) == lib.fsn_mlp_blob_bytes(C.byref(desc), 2) > 2_000_000
+    assert lib.fsn_mlp_blob_bytes(C.byref(desc), 1) < lib.fsn_mlp_blob_bytes(C.byref(desc), 0)
+    assert lib.fsn_mlp_blob_bytes(C.byref(desc), 7) == -1
+    a = L.RenderArgs()
+    a.R, a.S, a.n_imp = 0, 64, 128
+    assert lib.fsn_render_rays_fused(C.byref(desc), 2, None, None, C.byref(a), None) == 0  # zero rays: no-op
+    a.R, a.S = 10, 600
+    assert lib.fsn_render_rays_fused(C.byref(desc), 2, None, None, C.byref(a), None) < 0
+
+
+def test_host_layer_has_no_cpu_fallback():
+    from fs_nerf_amd.core.models import NeRF, PositionalEncoder
+    from fs_nerf_amd.utils import utilities as U
+    with pytest.raises(RuntimeError):
+        PositionalEncoder(3, 4, True)(torch.zeros(5, 3))
+    with pytest.raises(RuntimeError):
+        U.get_rays(torch.eye(4), (4, 4, 2.0), torch.device("cpu"))
+    m = NeRF(3, 3, 4, 128, (4,), pos_fn={"n_freqs": 10, "log_space": True}, dir_fn={"n_freqs": 4, "log_space": True})
+    assert set(m.state_dict()) == {f"layers.{i}.{p}" for i in range(4) for p in ("weight", "bias")} | {
+        f"{n}.{p}" for n in ("sigma", "connection", "branch", "rgb") for p in ("weight", "bias")}
+    assert m.layers[1].weight.shape == (128, 128) and m.branch.weight.shape == (64, 128 + 27)
+    with pytest.raises(ValueError):
+        NeRF(3, 3, 8, 256, (7,), pos_fn={"n_freqs": 10, "log_space": True},
+             dir_fn={"n_freqs": 4, "log_space": True}).eval().packed()
+    assert U.get_chunks(torch.zeros(10, 3), 4)[-1].shape == (2, 3)

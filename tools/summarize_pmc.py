@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Summarise the rocprofv3 PMC passes collected by profiles_run_pmc.sh into profiles/<tag>_pmc_summary.json
+(+ a copy of the per-kernel rows).  usage: python tools/summarize_pmc.py <tag> [kernel-substring]"""
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+kern = sys.argv[2] if len(sys.argv) > 2 else "k_render_fused"
+src = os.path.join(ROOT, "gpurun_out", f"pmc_{tag}")
+tot, ndisp, dur = {}, {}, []
+for p in sorted(glob.glob(os.path.join(src, "p*", "*", "*counter_collection.csv"))):
+    seen = set()
+    for r in csv.DictReader(open(p)):
+        if kern not in r["Kernel_Name"]:
+            continue
+        tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        seen.add(r["Dispatch_Id"])
+        dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9)
+    for c in {r for r in tot}:
+        ndisp.setdefault(c, max(len(seen), 1))
+n = 1  # bench.py --steps 1 --warmup 0: one launch per pass
+out = {"kernel": kern, "launches_per_pass": n, "counters_per_launch": {k: v / n for k, v in sorted(tot.items())}}
+c = out["counters_per_launch"]
+if dur:
+    out["kernel_seconds_profiled"] = sum(dur) / len(dur)
+if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+    # MI355X_MICROARCH.md, HBM: FETCH_SIZE/WRITE_SIZE are KiB of L2<->fabric requests; on gfx950 FETCH_SIZE reads
+    # exactly half of a wide (16 B/lane) coalesced stream -> doubled; WRITE_SIZE is exact.  Infinity-Cache hits are
+    # included (the weight stream is served from L2 / Infinity Cache, so this is an upper bound on HBM bytes).
+    out["k_render_fused_hbm_bytes_per_launch"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+    out["fetch_bytes_corrected"] = 2.0 * c["FETCH_SIZE"] * 1024.0
+    out["write_bytes"] = c["WRITE_SIZE"] * 1024.0
+if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
+    cyc = c["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
+    out["kernel_cycles"] = cyc
+    out["mfma_busy_frac"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc)
+    if dur:
+        out["clock_ghz"] = cyc / out["kernel_seconds_profiled"] / 1e9
+if "TCC_HIT_sum" in c:
+    out["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS"):
+    if k in c and "SQ_WAVE_CYCLES" in c:
+        out[k.lower() + "_frac_of_wave_cycles"] = c[k] / c["SQ_WAVE_CYCLES"]
+os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+dst = os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json")
+json.dump(out, open(dst, "w"), indent=1)
+print(json.dumps(out, indent=1))
