@@ -153,14 +153,14 @@ struct TileSrc {
 };
 
 // Persistent workgroups; tile = 128 consecutive samples; wave w / lane (r,h) owns sample
-// 128*tile + 32*w + r.  LDS: [weight ring 64 KiB][aux + masks][tile inputs 128 x 6 floats].
+// 128*tile + 32*w + r.  LDS: [weight ring 64 KiB][encoding stash 32 KiB][aux + masks][tile inputs].
 template <int NT, int PREC, bool FULL>
 __global__ __launch_bounds__(256) void k_mlp_fwd(MlpFwdArgs a) {
-  __shared__ __attribute__((aligned(1024))) char smem[kRingBytes + (kAuxCapFloats + 96) * 4 + 128 * 6 * 4];
-  float* aux_lds = reinterpret_cast<float*>(smem + kRingBytes);
+  __shared__ __attribute__((aligned(1024))) char smem[kRingBytes + kPeStashBytes + (kAuxCapFloats + 96) * 4 + 128 * 6 * 4];
+  float* aux_lds = reinterpret_cast<float*>(smem + kRingBytes + kPeStashBytes);
   float* in_lds = aux_lds + kAuxCapFloats + 96;
   NetDev net;
-  load_net(a.net, a.pos_mask, a.dir_mask, aux_lds, net);
+  load_net(a.net, a.pos_mask, a.dir_mask, aux_lds, smem + kRingBytes, net);
   __syncthreads();
   constexpr bool full = FULL;
   const int64_t ntiles = (a.n + 127) / 128;

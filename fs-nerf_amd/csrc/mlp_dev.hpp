@@ -36,7 +36,8 @@ constexpr int kLead = FSN_LEAD;
 constexpr int kLook = kLead > 0 ? kNSlot - 2 : kNSlot - 1;
 constexpr int kGldsPerWave = kPhaseBytes / 1024 / 4;  // 1-KiB glds instructions per wave per phase
 constexpr int kRingBytes = kNSlot * kPhaseBytes;
-constexpr int kAuxCapFloats = 4096;  // LDS reserved per network for biases / heads
+constexpr int kAuxCapFloats = 3456;  // LDS reserved per network for biases / heads (8x256 needs 3392)
+constexpr int kPeStashBytes = 2 * kKsPos * 256 * 16;  // 32 KiB: every lane's positional-encoding operands
 
 struct Frag {  // one k-step (16 features x 32 samples) of activations as MFMA B operand
   s16x8 hi, lo;
@@ -186,6 +187,7 @@ struct NetDev {
   const float* aux;       // LDS copy of the blob's aux region
   const float* pos_mask;  // LDS, 64 floats (ones when no mask)
   const float* dir_mask;  // LDS, 32 floats
+  char* pe_stash;         // LDS, this lane's slot of the [2*kKsPos][256 lanes] x 16 B operand stash
   int32_t n_layers;
   uint32_t skip_mask;
   int32_t n_freqs_pos, n_freqs_dir;
@@ -289,14 +291,16 @@ __device__ __forceinline__ void unit_mfma(const char* ubase, const Frag& b, f32x
 //   EPI_LAST_*   : heads.sigma += w_sigma . relu(acc); _FULL also converts  (last hidden layer)
 //   EPI_CVT      : out = split(acc)                                             (connection)
 //   EPI_RGB      : heads.rgb[c] += w_rgb[c] . relu(acc)                        (branch)
-template <int PREC, int NT_OUT, int KS_ACT, int KS_ENC, int EPI, int NACT, int NENC, int NOUT>
+// ENC_LDS: the encoding operands are read back from this lane's LDS stash (written once per tile by
+// mlp_tile) instead of occupying 32 registers through the widest layer of the network.
+template <int PREC, int NT_OUT, int KS_ACT, int KS_ENC, int EPI, bool ENC_LDS, int NACT, int NENC, int NOUT>
 __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int aux_bias, const Frag (&act)[NACT],
                                            const Frag (&enc)[NENC], Frag (&out)[NOUT], Heads& heads, int h) {
   constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
   constexpr int UPP = X3 ? 8 : 16;
   constexpr int UB = X3 ? 2048 : 1024;
   constexpr int KS = KS_ACT + KS_ENC;
-  static_assert(KS_ACT <= NACT && KS_ENC <= NENC, "operand arrays too small");
+  static_assert(KS_ACT <= NACT && (ENC_LDS || KS_ENC <= NENC), "operand arrays too small");
   const float* bias = net.aux + aux_bias;
 #pragma unroll
   for (int t = 0; t < NT_OUT; ++t) {
@@ -317,13 +321,25 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
         st.open_next();
       if (u % UPP == 0) st.enter_phase();
       const char* ub = st.c_base + (u % UPP) * UB;
-      if (ks < KS_ACT) unit_mfma<PREC>(ub, act[ks < KS_ACT ? ks : 0], acc);
-      else unit_mfma<PREC>(ub, enc[ks >= KS_ACT ? ks - KS_ACT : 0], acc);
+      if (ks < KS_ACT) {
+        unit_mfma<PREC>(ub, act[ks < KS_ACT ? ks : 0], acc);
+      } else if (ENC_LDS) {
+        Frag e;
+        const int k = ks - KS_ACT;
+        e.hi = *reinterpret_cast<const s16x8*>(net.pe_stash + (2 * k) * 4096);
+        if (X3) e.lo = *reinterpret_cast<const s16x8*>(net.pe_stash + (2 * k + 1) * 4096);
+        unit_mfma<PREC>(ub, e, acc);
+      } else {
+        unit_mfma<PREC>(ub, enc[ks >= KS_ACT ? ks - KS_ACT : 0], acc);
+      }
     }
     // ---- epilogue of tile t
     if (EPI == EPI_RELU_CVT || EPI == EPI_LAST_FULL || EPI == EPI_LAST_DENS || EPI == EPI_RGB) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = fmaxf(acc[i], 0.f);
+      for (int i = 0; i < 16; ++i) {  // relu on the sign bit: one v_max_i32, no canonicalising pre-max as fmaxf has
+        const int b = __builtin_bit_cast(int, (float)acc[i]);
+        acc[i] = __builtin_bit_cast(float, b < 0 ? 0 : b);
+      }
     }
     if (EPI == EPI_LAST_FULL || EPI == EPI_LAST_DENS) {
       const float* ws = net.aux + (net.n_layers + 2) * (NT_OUT * 32);
@@ -367,10 +383,10 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
 
 // ---------------------------------------------------------------- whole network, one tile
 // `src` supplies this lane's sample on demand: src.pos(x,y,z) and src.dir(x,y,z) (lanes l and l+32
-// hold the same sample).  The position is re-read and re-encoded at every wide (skip) layer
-// instead of keeping its 32 operand registers alive across the hidden layers, and the direction
-// is read only in front of the branch layer: the register file (512 per lane) is the scarce
-// resource of this kernel.  Outputs (valid in all lanes): sigma, and rgb when FULL.
+// hold the same sample).  The encoded position is parked in LDS for the wide (skip) layers instead
+// of keeping its 32 operand registers alive across the hidden layers, and the direction is read
+// only in front of the branch layer: the register file (512 per lane) is the scarce resource of
+// this kernel.  Outputs (valid in all lanes): sigma, and rgb when FULL.
 template <int NT, int PREC, bool FULL, class Src>
 __device__ __forceinline__ void mlp_tile(WStream& st, const NetDev& net, const Src& src, float& sigma,
                                          float (&rgb)[3]) {
@@ -388,19 +404,21 @@ __device__ __forceinline__ void mlp_tile(WStream& st, const NetDev& net, const S
     float px, py, pz;
     src.pos(px, py, pz);
     encode<kKsPos, F16, X3>(px, py, pz, net.n_freqs_pos, misc + 4, net.pos_mask, h, pe);
-    gemm_layer<PREC, NT, 0, kKsPos, EPI_RELU_CVT>(st, net, 0, none, pe, A, heads, h);
+    if (net.skip_mask) {  // park the operands for the wide (skip) layers in this lane's LDS slot
+#pragma unroll
+      for (int k = 0; k < kKsPos; ++k) {
+        *reinterpret_cast<s16x8*>(net.pe_stash + (2 * k) * 4096) = pe[k].hi;
+        if (X3) *reinterpret_cast<s16x8*>(net.pe_stash + (2 * k + 1) * 4096) = pe[k].lo;
+      }
+    }
+    gemm_layer<PREC, NT, 0, kKsPos, EPI_RELU_CVT, false>(st, net, 0, none, pe, A, heads, h);
   }
-#define FSN_HIDDEN(EPI, IN, OUT, LIDX)                                                                     \
-  do {                                                                                                     \
-    if ((net.skip_mask >> ((LIDX)-1)) & 1u) {                                                              \
-      Frag pe[kKsPos];                                                                                     \
-      float px, py, pz;                                                                                    \
-      src.pos(px, py, pz);                                                                                 \
-      encode<kKsPos, F16, X3>(px, py, pz, net.n_freqs_pos, misc + 4, net.pos_mask, h, pe);                 \
-      gemm_layer<PREC, NT, NA, kKsPos, EPI>(st, net, (LIDX)*D, IN, pe, OUT, heads, h);                     \
-    } else {                                                                                               \
-      gemm_layer<PREC, NT, NA, 0, EPI>(st, net, (LIDX)*D, IN, none, OUT, heads, h);                        \
-    }                                                                                                      \
+#define FSN_HIDDEN(EPI, IN, OUT, LIDX)                                                              \
+  do {                                                                                              \
+    if ((net.skip_mask >> ((LIDX)-1)) & 1u)                                                         \
+      gemm_layer<PREC, NT, NA, kKsPos, EPI, true>(st, net, (LIDX)*D, IN, none, OUT, heads, h);      \
+    else                                                                                            \
+      gemm_layer<PREC, NT, NA, 0, EPI, false>(st, net, (LIDX)*D, IN, none, OUT, heads, h);          \
   } while (0)
   for (int l = 1; l <= L - 2; l += 2) {
     FSN_HIDDEN(EPI_RELU_CVT, A, B, l);
@@ -417,12 +435,12 @@ __device__ __forceinline__ void mlp_tile(WStream& st, const NetDev& net, const S
   sigma = heads.sigma + __shfl_xor(heads.sigma, 32, 64) + misc[0];
   if (FULL) {
     // connection (no activation, models.py:130), then branch on [feat, dir_enc] (models.py:131-133)
-    gemm_layer<PREC, NT, NA, 0, EPI_CVT>(st, net, L * D, B, none, A, heads, h);
+    gemm_layer<PREC, NT, NA, 0, EPI_CVT, false>(st, net, L * D, B, none, A, heads, h);
     Frag de[kKsDir];
     float dx, dy, dz;
     src.dir(dx, dy, dz);
     encode<kKsDir, F16, X3>(dx, dy, dz, net.n_freqs_dir, misc + 20, net.dir_mask, h, de);
-    gemm_layer<PREC, NT / 2, NA, kKsDir, EPI_RGB>(st, net, (L + 1) * D, A, de, B, heads, h);
+    gemm_layer<PREC, NT / 2, NA, kKsDir, EPI_RGB, false>(st, net, (L + 1) * D, A, de, B, heads, h);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float z = heads.rgb[c] + __shfl_xor(heads.rgb[c], 32, 64) + misc[1 + c];
@@ -432,9 +450,11 @@ __device__ __forceinline__ void mlp_tile(WStream& st, const NetDev& net, const S
 }
 
 // Copy a blob's aux region and the two frequency masks into LDS (all threads of the workgroup;
-// the caller synchronises afterwards) and describe the net.  lds: aux_floats + 96 floats.
+// the caller synchronises afterwards) and describe the net.  lds: aux_floats + 96 floats;
+// pe_stash: kPeStashBytes of LDS shared by both networks of a kernel.
 __device__ __forceinline__ void load_net(const NetParams& p, const float* __restrict__ pos_mask_g,
-                                         const float* __restrict__ dir_mask_g, float* lds, NetDev& net) {
+                                         const float* __restrict__ dir_mask_g, float* lds, char* pe_stash,
+                                         NetDev& net) {
   const f32x4* src = reinterpret_cast<const f32x4*>(p.blob + p.aux_off);
   f32x4* dst = reinterpret_cast<f32x4*>(lds);
   for (int i = threadIdx.x; i < p.aux_floats / 4; i += blockDim.x) dst[i] = src[i];
@@ -446,6 +466,7 @@ __device__ __forceinline__ void load_net(const NetParams& p, const float* __rest
   net.aux = lds;
   net.pos_mask = pm;
   net.dir_mask = dm;
+  net.pe_stash = pe_stash + threadIdx.x * 16;
   net.n_layers = p.n_layers;
   net.skip_mask = p.skip_mask;
   net.n_freqs_pos = p.n_freqs_pos;

@@ -12,8 +12,8 @@
 
 namespace fsn {
 
-constexpr int kMaxGroupSamples = 512;  // G * (S + n_imp) <= this
-constexpr int kMaxRaySamples = 512;    // S + n_imp <= this
+constexpr int kMaxGroupSamples = 384;  // G * (S + n_imp) <= this
+constexpr int kMaxRaySamples = 384;    // S + n_imp <= this
 constexpr int kMaxG = 8;
 
 struct RenderKArgs {
@@ -36,7 +36,7 @@ struct RenderLds {
 };
 
 constexpr int kNetLdsBytes = (kAuxCapFloats + 96) * 4;
-constexpr int kRenderLdsBytes = kRingBytes + 2 * kNetLdsBytes + (int)sizeof(RenderLds);
+constexpr int kRenderLdsBytes = kRingBytes + kPeStashBytes + 2 * kNetLdsBytes + (int)sizeof(RenderLds);
 static_assert(kRenderLdsBytes <= 160 * 1024, "LDS budget");
 
 // sample source of the fused kernel: interval midpoint on the ray, x = o + d*(t0+t1)/2
@@ -56,15 +56,16 @@ struct RaySrc {
 template <int NT, int PREC>
 __global__ __launch_bounds__(256) void k_render_fused(RenderKArgs k) {
   __shared__ __attribute__((aligned(1024))) char smem[kRenderLdsBytes];
-  float* auxC = reinterpret_cast<float*>(smem + kRingBytes);
-  float* auxF = reinterpret_cast<float*>(smem + kRingBytes + kNetLdsBytes);
-  RenderLds& S_ = *reinterpret_cast<RenderLds*>(smem + kRingBytes + 2 * kNetLdsBytes);
+  char* stash = smem + kRingBytes;
+  float* auxC = reinterpret_cast<float*>(stash + kPeStashBytes);
+  float* auxF = reinterpret_cast<float*>(stash + kPeStashBytes + kNetLdsBytes);
+  RenderLds& S_ = *reinterpret_cast<RenderLds*>(stash + kPeStashBytes + 2 * kNetLdsBytes);
   const fsn_render_args& a = k.a;
   const int S = a.S, NI = a.n_imp, So = S + NI, G = k.G;
   const bool hier = NI > 0;
   NetDev netC, netF;
-  load_net(k.netF, a.pos_mask, a.dir_mask, auxF, netF);
-  if (hier) load_net(k.netC, a.pos_mask, a.dir_mask, auxC, netC);
+  load_net(k.netF, a.pos_mask, a.dir_mask, auxF, stash, netF);
+  if (hier) load_net(k.netC, a.pos_mask, a.dir_mask, auxC, stash, netC);
   else netC = netF;
   __syncthreads();
   WStream st;
