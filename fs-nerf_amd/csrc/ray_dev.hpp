@@ -122,7 +122,7 @@ __device__ __forceinline__ float linspace01(int i, int n) {
 // Hierarchical resampling for ONE ray by ONE wave (build's definition, oracle sample_pdf +
 // merge_edges): inverse-CDF samples of pdf=(max(w,0)+1e-5)/sum over `edges`, merged with the
 // edges and sorted ascending into out[S+1+n_imp].  cdf_s (>= S+1 floats) and vals_s
-// (>= S+1+n_imp floats) are this wave's LDS scratch; u is [n_imp] or null (deterministic).
+// (>= S+1+pow2ceil(n_imp) floats) are this wave's LDS scratch; u is [n_imp] or null (deterministic).
 __device__ __forceinline__ void sample_pdf_merge_ray(const float* __restrict__ edges,
                                                      const float* __restrict__ w, int S, int n_imp,
                                                      const float* __restrict__ u, float* cdf_s,
@@ -160,16 +160,50 @@ __device__ __forceinline__ void sample_pdf_merge_ray(const float* __restrict__ e
     vals_s[S + 1 + k] = e0 + (uk - c0) / denom * (e1 - e0);
   }
   __builtin_amdgcn_wave_barrier();
-  // rank sort: position = #{j : v_j < v_i or (v_j == v_i and j < i)}
-  const int M = S + 1 + n_imp;
-  for (int i = lane; i < M; i += 64) {
-    const float v = vals_s[i];
-    int rank = 0;
-    for (int j = 0; j < M; ++j) {
-      const float x = vals_s[j];
-      rank += (x < v || (x == v && j < i)) ? 1 : 0;
+  float* smp = vals_s + (S + 1);  // the n_imp importance samples
+  // Deterministic u is increasing and the inverse CDF is monotone, so the samples are normally sorted
+  // already; explicit (random) u leaves them unordered.  Check, and sort only when needed.
+  bool unsorted = false;
+  for (int k = lane; k + 1 < n_imp; k += 64) unsorted |= smp[k] > smp[k + 1];
+  if (__any(unsorted)) {
+    // bitonic sort in LDS, padded with +inf to a power of two
+    int n2 = 1;
+    while (n2 < n_imp) n2 <<= 1;
+    for (int k = n_imp + lane; k < n2; k += 64) smp[k] = __builtin_huge_valf();
+    __builtin_amdgcn_wave_barrier();
+    for (int k = 2; k <= n2; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = lane; i < n2; i += 64) {
+          const int l = i ^ j;
+          if (l > i) {
+            const float a = smp[i], b = smp[l];
+            const bool up = (i & k) == 0;
+            if ((a > b) == up) { smp[i] = b; smp[l] = a; }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
     }
-    out[rank] = v;
+  }
+  // Merge of two sorted lists by rank: an edge goes to (its index + #samples strictly below it), a
+  // sample to (its index + #edges <= it): a permutation for any ties, O(log n) LDS reads per element.
+  for (int i = lane; i <= S; i += 64) {
+    const float v = vals_s[i];
+    int lo = 0, hi = n_imp;  // lower_bound over the sorted samples
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (smp[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    out[i + lo] = v;
+  }
+  for (int k = lane; k < n_imp; k += 64) {
+    const float v = smp[k];
+    int lo = 0, hi = S + 1;  // upper_bound over the sorted edges
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (vals_s[mid] <= v) lo = mid + 1; else hi = mid;
+    }
+    out[k + lo] = v;
   }
 }
 

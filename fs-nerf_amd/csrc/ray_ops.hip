@@ -102,7 +102,9 @@ __global__ void k_edges_to_packed(const float* __restrict__ edges, int64_t R, in
   t1[e] = edges[r * (S + 1) + i + 1];
 }
 
-// one wave per ray, 4 rays per 256-thread block; dynamic LDS = 4 * (2*S+2+n_imp) floats
+static inline int pow2ceil(int n) { int p = 1; while (p < n) p <<= 1; return p; }
+
+// one wave per ray, 4 rays per 256-thread block; dynamic LDS = 4 * (2*S+2+pow2ceil(n_imp)) floats
 __global__ void k_sample_pdf_merge(const float* __restrict__ edges, const float* __restrict__ w, int64_t R,
                                    int S, int n_imp, const float* __restrict__ u, float* __restrict__ out) {
   extern __shared__ float smem[];
@@ -110,7 +112,9 @@ __global__ void k_sample_pdf_merge(const float* __restrict__ edges, const float*
   const int64_t r = (int64_t)blockIdx.x * 4 + wave;
   if (r >= R) return;
   const int M = S + 1 + n_imp;
-  float* cdf_s = smem + (size_t)wave * (S + 1 + M);
+  int n2 = 1;
+  while (n2 < n_imp) n2 <<= 1;
+  float* cdf_s = smem + (size_t)wave * (2 * S + 2 + n2);
   float* vals_s = cdf_s + (S + 1);
   sample_pdf_merge_ray(edges + r * (S + 1), w + r * S, S, n_imp, u ? u + r * n_imp : nullptr, cdf_s, vals_s,
                        out + r * M);
@@ -235,7 +239,7 @@ extern "C" int fsn_sample_pdf_merge(const float* edges, const float* weights, in
   FSN_REQUIRE(S > 0 && R >= 0 && n_imp >= 0, FSN_E_INVALID, "fsn_sample_pdf_merge: bad sizes");
   if (R == 0) return FSN_OK;
   FSN_REQUIRE(edges && weights && edges_out, FSN_E_INVALID, "fsn_sample_pdf_merge: null pointer");
-  const size_t lds = 4 * (size_t)(2 * S + 2 + n_imp) * sizeof(float);
+  const size_t lds = 4 * (size_t)(2 * S + 2 + pow2ceil(n_imp)) * sizeof(float);
   FSN_REQUIRE(lds <= 64 * 1024, FSN_E_UNSUPPORTED, "fsn_sample_pdf_merge: S=%d n_imp=%d too large", S, n_imp);
   k_sample_pdf_merge<<<nblocks(R, 4), 256, lds, as_stream(stream)>>>(edges, weights, R, S, n_imp, u, edges_out);
   FSN_LAUNCH_CHECK("k_sample_pdf_merge");

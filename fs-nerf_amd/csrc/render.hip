@@ -192,6 +192,12 @@ extern "C" int fsn_render_rays_fused(const fsn_mlp_desc* desc, int prec, const v
   FSN_REQUIRE(a.u_mode == 0 || a.u, FSN_E_INVALID, "fsn_render_rays_fused: u_mode %d needs u", a.u_mode);
   const int So = a.S + a.n_imp;
   FSN_REQUIRE(So <= kMaxRaySamples, FSN_E_UNSUPPORTED, "fsn_render_rays_fused: S+n_imp=%d > %d", So, kMaxRaySamples);
+  {
+    int n2 = 1;
+    while (n2 < a.n_imp) n2 <<= 1;  // the resampler's sort scratch is padded to a power of two
+    FSN_REQUIRE(a.S + n2 <= kMaxRaySamples, FSN_E_UNSUPPORTED, "fsn_render_rays_fused: S + pow2ceil(n_imp) = %d > %d",
+                a.S + n2, kMaxRaySamples);
+  }
   FSN_REQUIRE(G.aux_floats <= kAuxCapFloats, FSN_E_UNSUPPORTED, "fsn_render_rays_fused: network too deep for LDS");
   RenderKArgs k;
   k.netF = net_params(*desc, G, blob_fine);
