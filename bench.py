@@ -69,7 +69,12 @@ def orbit_pose(phi_deg):
 def cpu_baseline(target_s=15.0):
     """Oracle (kind 'port') on the host cores, bounded sample of the same workload."""
     from oracle import fsnerf_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the GPU box gives one GPU's share of the host: 16 cores (os.cpu_count() reports the whole machine)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(int(os.environ.get("FSN_CPU_THREADS", min(avail, 16))))
     sd_c = O.init_nerf_state_dict(8, 256, [4], 10, 4, seed=42)
     sd_f = O.init_nerf_state_dict(8, 256, [4], 10, 4, seed=43)
     for sd in (sd_c, sd_f):
