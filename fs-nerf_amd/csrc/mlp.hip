@@ -36,13 +36,14 @@ FSN_HD void pack_piece(const PackArgs& a, int64_t piece, uint16_t out8[8]) {
   while (g + 1 < a.G.n_gemm && a.G.g[g + 1].unit0 <= unit) ++g;
   const LayerGeom& Lg = a.G.g[g];
   const int ks_tot = Lg.ks_act + Lg.ks_enc;
-  const int lu = unit - Lg.unit0;
-  const int t = lu / ks_tot, ks = lu - t * ks_tot;
-  const int r = lane & 31, h = lane >> 5;
+  const int lu = unit - Lg.unit0;          // ((pair * ks_tot) + ks) * 2 + half
+  const int sub = lu & 1;
+  const int t = (lu >> 1) / ks_tot, ks = (lu >> 1) - t * ks_tot;
+  const int r = lane & 15, grp = lane >> 4;
   const float* W = a.W[gemm_to_sd(g, a.n_layers)];
-  const int row = 32 * t + r;
+  const int row = 32 * t + 16 * sub + r;
   for (int j = 0; j < 8; ++j) {
-    const int col = unit_src_col(Lg, ks, h, j);
+    const int col = unit_src_col(Lg, ks, grp, j);
     if (col < 0) continue;
     const float w = W[(int64_t)row * Lg.ld + col];
     const bool f16 = prec_is_f16(a.prec);
@@ -152,15 +153,15 @@ struct TileSrc {
   __device__ __forceinline__ void dir(float& x, float& y, float& z) const { x = p[3]; y = p[4]; z = p[5]; }
 };
 
-// Persistent workgroups; tile = 128 consecutive samples; wave w / lane (r,h) owns sample
-// 128*tile + 32*w + r.  LDS: [weight ring 64 KiB][encoding stash 32 KiB][aux + masks][tile inputs].
+// Persistent workgroups; tile = 128 consecutive samples; wave w / lane (c = lane&15, g = lane>>4)
+// owns sample 128*tile + 16*w + c.  LDS: [weight ring 64 KiB][aux + masks][tile inputs 128 x 6 floats].
 template <int NT, int PREC, bool FULL>
-__global__ __launch_bounds__(256) void k_mlp_fwd(MlpFwdArgs a) {
-  __shared__ __attribute__((aligned(1024))) char smem[kRingBytes + kPeStashBytes + (kAuxCapFloats + 96) * 4 + 128 * 6 * 4];
-  float* aux_lds = reinterpret_cast<float*>(smem + kRingBytes + kPeStashBytes);
+__global__ __launch_bounds__(kThreads) void k_mlp_fwd(MlpFwdArgs a) {
+  __shared__ __attribute__((aligned(1024))) char smem[kRingBytes + (kAuxCapFloats + 96) * 4 + 128 * 6 * 4];
+  float* aux_lds = reinterpret_cast<float*>(smem + kRingBytes);
   float* in_lds = aux_lds + kAuxCapFloats + 96;
   NetDev net;
-  load_net(a.net, a.pos_mask, a.dir_mask, aux_lds, smem + kRingBytes, net);
+  load_net(a.net, a.pos_mask, a.dir_mask, aux_lds, net);
   __syncthreads();
   constexpr bool full = FULL;
   const int64_t ntiles = (a.n + 127) / 128;
@@ -169,18 +170,18 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(MlpFwdArgs a) {
   st.init(smem, nullptr, 0, 0, sbase, (uint32_t)(full ? a.net.nph_full : a.net.nph_density), 1);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t s = tile * 128 + wave * 32 + (lane & 31);
+    const int64_t s = tile * 128 + wave * 16 + (lane & 15);
     const int64_t sc = s < a.n ? s : a.n - 1;
-    if (lane < 32) {  // each wave stages (and later reads) only its own 32 samples: no workgroup barrier
-      float* q = in_lds + (wave * 32 + lane) * 6;
+    if (lane < 16) {  // each wave stages (and later reads) only its own 16 samples: no workgroup barrier
+      float* q = in_lds + (wave * 16 + lane) * 6;
       q[0] = a.x[3 * sc]; q[1] = a.x[3 * sc + 1]; q[2] = a.x[3 * sc + 2];
       if (full) { q[3] = a.dirs[3 * sc]; q[4] = a.dirs[3 * sc + 1]; q[5] = a.dirs[3 * sc + 2]; }
     }
     __builtin_amdgcn_wave_barrier();
-    const TileSrc src{in_lds + (wave * 32 + (lane & 31)) * 6};
+    const TileSrc src{in_lds + (wave * 16 + (lane & 15)) * 6};
     float sigma, rgb[3] = {0.f, 0.f, 0.f};
     mlp_tile<NT, PREC, FULL>(st, net, src, sigma, rgb);
-    if (lane < 32 && s < a.n) {
+    if (lane < 16 && s < a.n) {
       if (full) {
         f32x4 o = {rgb[0], rgb[1], rgb[2], sigma};
         *reinterpret_cast<f32x4*>(a.out + 4 * s) = o;
@@ -196,8 +197,8 @@ template <int NT, int PREC>
 static int launch_mlp_fwd(const MlpFwdArgs& a, int cus, hipStream_t s) {
   const int64_t ntiles = (a.n + 127) / 128;
   const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
-  if (a.dirs) k_mlp_fwd<NT, PREC, true><<<grid, 256, 0, s>>>(a);
-  else k_mlp_fwd<NT, PREC, false><<<grid, 256, 0, s>>>(a);
+  if (a.dirs) k_mlp_fwd<NT, PREC, true><<<grid, kThreads, 0, s>>>(a);
+  else k_mlp_fwd<NT, PREC, false><<<grid, kThreads, 0, s>>>(a);
   FSN_LAUNCH_CHECK("k_mlp_fwd");
   return FSN_OK;
 }

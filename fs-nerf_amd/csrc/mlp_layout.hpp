@@ -3,15 +3,17 @@
 //
 // The NeRF MLP (src/core/models.py:96-143) is evaluated TRANSPOSED on the matrix cores:
 //   H_out^T [features x samples] = W [out x in] . H_in^T [in x samples]
-// with v_mfma_f32_32x32x16_bf16: A = a 32(out) x 16(in) weight fragment, B = a 16(in) x 32
-// (samples) activation fragment, D = a 32(out) x 32(samples) fp32 accumulator tile whose
-// layout (column = lane&31 = sample, row = (reg&3)+8(reg>>2)+4(lane>>5) = out feature) is
-// exactly the B-operand layout of the next layer, so activations never leave registers.
+// with v_mfma_f32_16x16x32_{f16,bf16}: A = a 16(out) x 32(in) weight fragment, B = a 32(in) x 16
+// (samples) activation fragment, D = a 16(out) x 16(samples) fp32 accumulator tile with
+// column = lane&15 = sample and row = 4(lane>>4) + reg = out feature.  Two such tiles (32 features)
+// hold, lane for lane, exactly the 8 elements a lane needs as B operand of one k-step of the next
+// layer, so activations never leave registers.
 //
-// A "unit" is the A operand of one (layer, out-tile t, k-step ks): one 1-KiB fragment of the
-// 16-bit (bf16 or fp16) high parts and, in the x3 modes, one 1-KiB fragment of the low parts, lane-linear
-// (lane l owns bytes [16 l, 16 l + 16)).  Units are stored in the order the kernel consumes
-// them (layer, then out-tile, then k-step) and streamed through LDS in 16-KiB "phases".
+// A "unit" is the A operand of one (layer, 32-feature output pair tp, k-step ks, half sub): one
+// 1-KiB fragment of the 16-bit (bf16 or fp16) high parts and, in the x3 modes, one 1-KiB fragment
+// of the low parts, lane-linear (lane l owns bytes [16 l, 16 l + 16)).  Units are stored in the
+// order the kernel consumes them (layer, pair, k-step, half) and streamed through LDS in 16-KiB
+// "phases".
 #pragma once
 #include <cstdint>
 
@@ -27,8 +29,8 @@ namespace fsn {
 
 constexpr uint32_t kBlobMagic = 0x4e53460au;  // "\nFSN"
 constexpr int kPhaseBytes = 16384;
-constexpr int kKsPos = 4;  // k-steps (of 16) reserved for the positional encoding: 64 slots
-constexpr int kKsDir = 2;  // k-steps reserved for the direction encoding: 32 slots
+constexpr int kKsPos = 2;  // k-steps (of 32) reserved for the positional encoding: 64 slots
+constexpr int kKsDir = 1;  // k-steps reserved for the direction encoding: 32 slots
 constexpr int kMaxLayers = 16;
 
 FSN_HD bool prec_is_x3(int prec) { return (prec & 1) == 0; }
@@ -38,8 +40,8 @@ FSN_HD int units_per_phase(int prec) { return kPhaseBytes / unit_bytes(prec); }
 
 // One GEMM of the network as the kernel sees it.
 struct LayerGeom {
-  int32_t nt_out;      // 32-row output tiles
-  int32_t ks_act;      // k-steps fed by the previous layer's activations (2 per 32 features)
+  int32_t nt_out;      // 32-feature output pairs (two 16-row MFMA tiles each)
+  int32_t ks_act;      // k-steps (of 32) fed by the previous layer's activations
   int32_t ks_enc;      // k-steps fed by an encoding (kKsPos / kKsDir) or 0
   int32_t enc_is_dir;  // which encoding
   int32_t n_freqs;     // of that encoding
@@ -62,34 +64,31 @@ struct NetGeom {
 
 // Encoding slot -> feature index of the reference's PositionalEncoder layout
 // (src/core/models.py:28,37-39: [x, sin f0 x, cos f0 x, sin f1 x, ...], blocks d_in=3 wide), or -1.
-// Half h (= lane>>5) of a sample's lane pair owns `slots` slots q = 8*ks + j.  Pair p = 3*band+coord
-// goes to half p&1 at slots (2i, 2i+1) = (sin, cos) with i = p>>1; the identity features x,y sit in
-// half 0's last two slots and z in half 1's second to last.
-FSN_HD int enc_slot_feature(int q, int h, int n_freqs, int slots) {
+// The four lanes g = lane>>4 that share a sample own `slots` = 8 * k-steps slots each, q = 8*ks + j.
+// Pair p = 3*band+coord goes to lane group p&3 at slots (2i, 2i+1) = (sin, cos), i = p>>2; the
+// identity features x, y sit in group 2's last two slots and z in group 3's second to last.
+FSN_HD int enc_slot_feature(int q, int g, int n_freqs, int slots) {
   const int P = 3 * n_freqs;
-  const int np = (P - h + 1) / 2;  // pairs owned by this half
-  if (q >= slots - 2) {
-    const int id = q - (slots - 2);
-    if (h == 0) return id;           // x, y
-    return id == 0 ? 2 : -1;          // z, pad
-  }
+  const int np = P > g ? (P - g + 3) / 4 : 0;  // pairs owned by this lane group
   if (q < 2 * np) {
-    const int p = 2 * (q >> 1) + h;
+    const int p = 4 * (q >> 1) + g;
     const int band = p / 3, coord = p - 3 * band;
     return 3 + band * 6 + (q & 1) * 3 + coord;
   }
+  if (g == 2 && q >= slots - 2) return q - (slots - 2);  // x, y
+  if (g == 3 && q == slots - 2) return 2;                // z
   return -1;
 }
 
-// Source column of weight fragment element (k-step ks, lane half h, element j) for a layer;
-// -1 = zero padding.  Activation k-steps use the accumulator-as-operand order
-//   feature = 32 (ks>>1) + 16 (ks&1) + 8 (j>>2) + 4 h + (j&3)
-// (cdna_hip_programming.md section 3, "An accumulator tile as the next MFMA's operand").
-FSN_HD int unit_src_col(const LayerGeom& L, int ks, int h, int j) {
-  if (ks < L.ks_act) return 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
+// Source column of weight fragment element (k-step ks, lane group g, element j) for a layer;
+// -1 = zero padding.  Activation k-steps use the accumulator-as-operand order: element j of lane
+// group g is register j&3 of output tile 2ks + (j>>2) of the previous layer, i.e.
+//   feature = 32 ks + 16 (j>>2) + 4 g + (j&3).
+FSN_HD int unit_src_col(const LayerGeom& L, int ks, int g, int j) {
+  if (ks < L.ks_act) return 32 * ks + 16 * (j >> 2) + 4 * g + (j & 3);
   const int e = ks - L.ks_act;
   const int slots = 8 * L.ks_enc;
-  const int f = enc_slot_feature(8 * e + j, h, L.n_freqs, slots);
+  const int f = enc_slot_feature(8 * e + j, g, L.n_freqs, slots);
   return f < 0 ? -1 : L.d_act + f;
 }
 
@@ -155,22 +154,22 @@ inline int build_geom(const fsn_mlp_desc& d, int prec, NetGeom& G, const char** 
     LayerGeom& g = G.g[l];
     const bool wide = l > 0 && ((d.skip_mask >> (l - 1)) & 1u);
     g.nt_out = NT;
-    g.ks_act = l == 0 ? 0 : 2 * NT;
+    g.ks_act = l == 0 ? 0 : NT;
     g.ks_enc = (l == 0 || wide) ? kKsPos : 0;
     g.enc_is_dir = 0;
     g.n_freqs = d.n_freqs_pos;
     g.d_act = l == 0 ? 0 : D;
     g.ld = g.d_act + (g.ks_enc ? d_pe : 0);
     g.unit0 = u;
-    u += g.nt_out * (g.ks_act + g.ks_enc);
+    u += 2 * g.nt_out * (g.ks_act + g.ks_enc);
   }
   G.units_hidden = u;
   LayerGeom& c = G.g[L];  // connection
-  c = LayerGeom{NT, 2 * NT, 0, 0, 0, D, D, u};
-  u += NT * 2 * NT;
+  c = LayerGeom{NT, NT, 0, 0, 0, D, D, u};
+  u += 2 * NT * NT;
   LayerGeom& b = G.g[L + 1];  // branch
-  b = LayerGeom{NT / 2, 2 * NT, kKsDir, 1, d.n_freqs_dir, D, D + d_de, u};
-  u += (NT / 2) * (2 * NT + kKsDir);
+  b = LayerGeom{NT / 2, NT, kKsDir, 1, d.n_freqs_dir, D, D + d_de, u};
+  u += 2 * (NT / 2) * (NT + kKsDir);
   G.n_gemm = L + 2;
   G.units_total = u;
   const int upp = units_per_phase(prec);

@@ -1,7 +1,7 @@
 // render.hip — the whole hot path of render_rays (src/render/rendering.py:25-107) in ONE launch:
 //   stratified interval edges -> [density pass of the coarse net -> per-ray weights (wave scan)
 //   -> inverse-CDF resampling + sorted union] -> full pass of the fine net -> alpha compositing.
-// A workgroup (4 waves) owns a group of G rays; sample positions, densities, colours, weights
+// A workgroup (8 waves, two per SIMD) owns a group of G rays; sample positions, densities, colours, weights
 // and the resampled edges live in LDS; the two MLP passes run on the matrix cores
 // (mlp_dev.hpp) with the weight stream continuing seamlessly from pass to pass and from ray
 // group to ray group; per-ray scans/reductions are done by one wavefront per ray (ray_dev.hpp).
@@ -14,7 +14,7 @@ namespace fsn {
 
 constexpr int kMaxGroupSamples = 384;  // G * (S + n_imp) <= this
 constexpr int kMaxRaySamples = 384;    // S + n_imp <= this
-constexpr int kMaxG = 8;
+constexpr int kMaxG = 4;
 
 struct RenderKArgs {
   NetParams netC, netF;
@@ -31,12 +31,12 @@ struct RenderLds {
   float edgesF[kMaxGroupSamples + kMaxG];
   float sigF[kMaxGroupSamples];
   float rgbF[3 * kMaxGroupSamples];
-  float cdf[4][kMaxRaySamples + 1];
-  float vals[4][kMaxRaySamples + 1];
+  float cdf[kMaxG][kMaxRaySamples + 1];
+  float vals[kMaxG][kMaxRaySamples + 1];
 };
 
 constexpr int kNetLdsBytes = (kAuxCapFloats + 96) * 4;
-constexpr int kRenderLdsBytes = kRingBytes + kPeStashBytes + 2 * kNetLdsBytes + (int)sizeof(RenderLds);
+constexpr int kRenderLdsBytes = kRingBytes + 2 * kNetLdsBytes + (int)sizeof(RenderLds);
 static_assert(kRenderLdsBytes <= 160 * 1024, "LDS budget");
 
 // sample source of the fused kernel: interval midpoint on the ray, x = o + d*(t0+t1)/2
@@ -54,18 +54,17 @@ struct RaySrc {
 };
 
 template <int NT, int PREC>
-__global__ __launch_bounds__(256) void k_render_fused(RenderKArgs k) {
+__global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
   __shared__ __attribute__((aligned(1024))) char smem[kRenderLdsBytes];
-  char* stash = smem + kRingBytes;
-  float* auxC = reinterpret_cast<float*>(stash + kPeStashBytes);
-  float* auxF = reinterpret_cast<float*>(stash + kPeStashBytes + kNetLdsBytes);
-  RenderLds& S_ = *reinterpret_cast<RenderLds*>(stash + kPeStashBytes + 2 * kNetLdsBytes);
+  float* auxC = reinterpret_cast<float*>(smem + kRingBytes);
+  float* auxF = reinterpret_cast<float*>(smem + kRingBytes + kNetLdsBytes);
+  RenderLds& S_ = *reinterpret_cast<RenderLds*>(smem + kRingBytes + 2 * kNetLdsBytes);
   const fsn_render_args& a = k.a;
   const int S = a.S, NI = a.n_imp, So = S + NI, G = k.G;
   const bool hier = NI > 0;
   NetDev netC, netF;
-  load_net(k.netF, a.pos_mask, a.dir_mask, auxF, stash, netF);
-  if (hier) load_net(k.netC, a.pos_mask, a.dir_mask, auxC, stash, netC);
+  load_net(k.netF, a.pos_mask, a.dir_mask, auxF, netF);
+  if (hier) load_net(k.netC, a.pos_mask, a.dir_mask, auxC, netC);
   else netC = netF;
   __syncthreads();
   WStream st;
@@ -82,7 +81,7 @@ __global__ __launch_bounds__(256) void k_render_fused(RenderKArgs k) {
       const int64_t ray = min(r0 + g, R - 1);
       S_.rays[tid] = c < 3 ? a.rays_o[3 * ray + c] : a.rays_d[3 * ray + c - 3];
     }
-    for (int e = tid; e < G * (S + 1); e += 256) {
+    for (int e = tid; e < G * (S + 1); e += kThreads) {
       const int g = e / (S + 1), i = e - g * (S + 1);
       const int64_t ray = min(r0 + g, R - 1);
       const float* ur = a.u_mode == 1 ? a.u + ray : (a.u_mode == 2 ? a.u + ray * (S + 1) : nullptr);
@@ -92,17 +91,17 @@ __global__ __launch_bounds__(256) void k_render_fused(RenderKArgs k) {
     if (hier) {
       // ---- density pass of the coarse net (sigma_fn, rendering.py:58-64)
       for (int sub = 0; sub < k.nsubC; ++sub) {
-        const int idx = sub * 128 + wave * 32 + (lane & 31);
+        const int idx = sub * 128 + wave * 16 + (lane & 15);
         const int idc = min(idx, G * S - 1);
         const int g = idc / S, i = idc - g * S;
         const RaySrc src{S_.rays + 6 * g, S_.edgesC + g * (S + 1) + i};
         float sigma, rgb[3];
         mlp_tile<NT, PREC, false>(st, netC, src, sigma, rgb);
-        if (lane < 32 && idx < G * S) S_.sigC[idx] = sigma;
+        if (lane < 16 && idx < G * S) S_.sigC[idx] = sigma;
       }
       lds_barrier();
       // ---- per-ray weights, inverse-CDF resampling, sorted union (one wave per ray)
-      for (int g = wave; g < G; g += 4) {
+      for (int g = wave; g < G; g += kWaves) {
         const int64_t ray = min(r0 + g, R - 1);
         float* wc = S_.wC + g * S;
         weights_ray(S_.sigC + g * S, S_.edgesC + g * (S + 1), S, wc);
@@ -110,20 +109,20 @@ __global__ __launch_bounds__(256) void k_render_fused(RenderKArgs k) {
         if (a.weights_coarse && r0 + g < R)
           for (int i = lane; i < S; i += 64) a.weights_coarse[ray * S + i] = wc[i];
         sample_pdf_merge_ray(S_.edgesC + g * (S + 1), wc, S, NI, a.u_fine ? a.u_fine + ray * NI : nullptr,
-                             S_.cdf[wave], S_.vals[wave], S_.edgesF + g * (So + 1));
+                             S_.cdf[g], S_.vals[g], S_.edgesF + g * (So + 1));
       }
       lds_barrier();
     }
     const float* edges = hier ? S_.edgesF : S_.edgesC;
     // ---- full pass of the fine net (rgb_sigma_fn, rendering.py:76-84)
     for (int sub = 0; sub < k.nsubF; ++sub) {
-      const int idx = sub * 128 + wave * 32 + (lane & 31);
+      const int idx = sub * 128 + wave * 16 + (lane & 15);
       const int idc = min(idx, G * So - 1);
       const int g = idc / So, i = idc - g * So;
       const RaySrc src{S_.rays + 6 * g, edges + g * (So + 1) + i};
       float sigma, rgb[3];
       mlp_tile<NT, PREC, true>(st, netF, src, sigma, rgb);
-      if (lane < 32 && idx < G * So) {
+      if (lane < 16 && idx < G * So) {
         S_.sigF[idx] = sigma;
         S_.rgbF[3 * idx + 0] = rgb[0];
         S_.rgbF[3 * idx + 1] = rgb[1];
@@ -132,7 +131,7 @@ __global__ __launch_bounds__(256) void k_render_fused(RenderKArgs k) {
     }
     lds_barrier();
     // ---- volume integration (nerfacc rendering arithmetic, rendering.py:89-96), one wave per ray
-    for (int g = wave; g < G; g += 4) {
+    for (int g = wave; g < G; g += kWaves) {
       if (r0 + g >= R) continue;
       const int64_t ray = r0 + g;
       const float* eg = edges + g * (So + 1);
@@ -156,7 +155,7 @@ template <int NT, int PREC>
 static int launch_render(const RenderKArgs& k, int cus, hipStream_t s) {
   const int64_t ngroups = (k.a.R + k.G - 1) / k.G;
   const unsigned grid = (unsigned)(ngroups < cus ? ngroups : cus);
-  k_render_fused<NT, PREC><<<grid, 256, 0, s>>>(k);
+  k_render_fused<NT, PREC><<<grid, kThreads, 0, s>>>(k);
   FSN_LAUNCH_CHECK("k_render_fused");
   return FSN_OK;
 }

@@ -1,9 +1,9 @@
 """CPU (no GPU): the packed-weights blob and the kernel's register dataflow.
 
 `fsn_mlp_pack_host` (the same index code as the device packer) packs a reference-format
-state_dict; a NumPy model of v_mfma_f32_32x32x16_bf16's documented lane layouts
+state_dict; a NumPy model of v_mfma_f32_16x16x32_{f16,bf16}'s documented lane layouts
 (cdna_hip_programming.md section 3) then replays exactly what fs-nerf_amd/csrc/mlp_dev.hpp does for one
-wavefront of 32 samples — encoding slots, unit order, accumulator-as-B-operand chaining,
+wavefront of 16 samples — encoding slots, unit order, accumulator-as-B-operand chaining,
 fp32 heads — and the result must equal the oracle's NeRF forward.  This pins the blob
 format and the chaining rule without a GPU."""
 import ctypes as C
@@ -41,7 +41,7 @@ def pack_host(sd, n_layers, d_hidden, skip, nf, nfd, prec):
 
 
 class Emu:
-    """One wavefront (64 lanes: sample r = lane & 31, half h = lane >> 5) of mlp_dev.hpp."""
+    """One wavefront (64 lanes: sample c = lane & 15, lane group g = lane >> 4) of mlp_dev.hpp."""
 
     def __init__(self, blob, prec):
         hw = blob[:256].view(np.uint32)
@@ -69,18 +69,19 @@ class Emu:
 
     @staticmethod
     def mfma(afrag, bfrag, acc):
-        """acc [16 regs, 64 lanes] += A.B with the 32x32x16 lane maps."""
-        A = np.zeros((32, 16))
-        B = np.zeros((16, 32))
+        """acc [4 regs, 64 lanes] += A.B with the 16x16x32 lane maps (cdna_hip_programming.md section 3):
+        A[row l&15][k = 8(l>>4)+j], B[k = 8(l>>4)+j][col l&15], D col = l&15, row = 4(l>>4)+reg."""
+        A = np.zeros((16, 32))
+        B = np.zeros((32, 16))
         for lane in range(64):
-            r, h = lane & 31, lane >> 5
-            A[r, 8 * h:8 * h + 8] = afrag[lane]
-            B[8 * h:8 * h + 8, r] = bfrag[lane]
+            r, g = lane & 15, lane >> 4
+            A[r, 8 * g:8 * g + 8] = afrag[lane]
+            B[8 * g:8 * g + 8, r] = bfrag[lane]
         Dm = A @ B
         for lane in range(64):
-            col, h = lane & 31, lane >> 5
-            for reg in range(16):
-                acc[reg, lane] += Dm[(reg & 3) + 8 * (reg >> 2) + 4 * h, col]
+            col, g = lane & 15, lane >> 4
+            for reg in range(4):
+                acc[reg, lane] += Dm[4 * g + reg, col]
         return acc
 
     def encode(self, xyz, n_freqs, freqs, mask, nks):
@@ -88,63 +89,68 @@ class Emu:
         v = np.zeros((64, slots))
         P = 3 * n_freqs
         for lane in range(64):
-            r, h = lane & 31, lane >> 5
-            x = xyz[r]
-            for i in range((slots - 2) // 2):
-                p = 2 * i + h
+            c, g = lane & 15, lane >> 4
+            x = xyz[c]
+            for i in range(slots // 2):
+                p = 4 * i + g
                 if p < P:
                     band, coord = divmod(p, 3)
                     a = np.float32(x[coord]) * np.float32(freqs[band])
                     v[lane, 2 * i] = np.sin(np.float64(a)) * mask[3 + band * 6 + coord]
                     v[lane, 2 * i + 1] = np.cos(np.float64(a)) * mask[3 + band * 6 + 3 + coord]
-            v[lane, slots - 2] = (x[2] * mask[2]) if h else (x[0] * mask[0])
-            v[lane, slots - 1] = 0.0 if h else x[1] * mask[1]
+            if g == 2:
+                v[lane, slots - 2], v[lane, slots - 1] = x[0] * mask[0], x[1] * mask[1]
+            if g == 3:
+                v[lane, slots - 2] = x[2] * mask[2]
         return [v[:, 8 * k:8 * k + 8] for k in range(nks)]
 
-    def layer(self, nt_out, act, enc, bias_off, relu):
-        outs, accs = [], []
-        for t in range(nt_out):
-            acc = np.zeros((16, 64))
+    def layer(self, np_out, act, enc, bias_off, relu):
+        """-> (B operands of the next layer, one per output pair; the pairs' 8 fp32 values per lane)"""
+        outs, vals = [], []
+        for tp in range(np_out):
+            acc = [np.zeros((4, 64)), np.zeros((4, 64))]
             for lane in range(64):
-                h = lane >> 5
-                for reg in range(16):
-                    acc[reg, lane] = self.aux[bias_off + 32 * t + 8 * (reg >> 2) + 4 * h + (reg & 3)]
+                g = lane >> 4
+                for reg in range(4):
+                    acc[0][reg, lane] = self.aux[bias_off + 32 * tp + 4 * g + reg]
+                    acc[1][reg, lane] = self.aux[bias_off + 32 * tp + 16 + 4 * g + reg]
             for b in list(act) + list(enc):
-                acc = self.mfma(self.a_frag(), b, acc)
+                for sub in range(2):
+                    acc[sub] = self.mfma(self.a_frag(), b, acc[sub])
+            v = np.concatenate([acc[0], acc[1]], axis=0)  # element j = register j&3 of tile j>>2
             if relu:
-                acc = np.maximum(acc, 0.0)
-            accs.append(acc)
-            outs.append(acc[0:8].T.copy())   # k-step 2t   : element j = register j
-            outs.append(acc[8:16].T.copy())  # k-step 2t+1 : element j = register 8 + j
-        return outs, accs
+                v = np.maximum(v, 0.0)
+            vals.append(v)
+            outs.append(v.T.copy())
+        return outs, vals
 
-    def head(self, accs, w_off, stride_t=32):
+    def head(self, vals, w_off):
         tot = np.zeros(64)
-        for t, acc in enumerate(accs):
+        for tp, v in enumerate(vals):
             for lane in range(64):
-                h = lane >> 5
-                for reg in range(16):
-                    tot[lane] += self.aux[w_off + 32 * t + 8 * (reg >> 2) + 4 * h + (reg & 3)] * acc[reg, lane]
-        return tot[:32] + tot[32:]
+                g = lane >> 4
+                for j in range(8):
+                    tot[lane] += self.aux[w_off + 32 * tp + 16 * (j >> 2) + 4 * g + (j & 3)] * v[j, lane]
+        return tot[:16] + tot[16:32] + tot[32:48] + tot[48:]
 
     def forward(self, x, dirs, pos_mask, dir_mask):
         L_, D = self.L, self.D
         misc = (L_ + 5) * D
         self.unit = 0
-        pe = self.encode(x, self.nf, self.aux[misc + 4:misc + 20], pos_mask, 4)
+        pe = self.encode(x, self.nf, self.aux[misc + 4:misc + 20], pos_mask, 2)
         act, _ = self.layer(self.NT, [], pe, 0, True)
         for l in range(1, L_):
             wide = (self.skip_mask >> (l - 1)) & 1
-            act, accs = self.layer(self.NT, act, pe if wide else [], l * D, True)
+            act, vals = self.layer(self.NT, act, pe if wide else [], l * D, True)
         assert self.unit * self.ub == self.nph_density * 16384
-        sigma = self.head(accs, (L_ + 2) * D) + self.aux[misc]
+        sigma = self.head(vals, (L_ + 2) * D) + self.aux[misc]
         if dirs is None:
             return sigma[:, None]
         act, _ = self.layer(self.NT, act, [], L_ * D, False)
-        de = self.encode(dirs, self.nfd, self.aux[misc + 20:misc + 36], dir_mask, 2)
-        _, accs = self.layer(self.NT // 2, act, de, (L_ + 1) * D, True)
+        de = self.encode(dirs, self.nfd, self.aux[misc + 20:misc + 36], dir_mask, 1)
+        _, vals = self.layer(self.NT // 2, act, de, (L_ + 1) * D, True)
         assert self.unit == self.units_total
-        rgb = [1.0 / (1.0 + np.exp(-(self.head(accs, (L_ + 3) * D + c * (D // 2)) + self.aux[misc + 1 + c])))
+        rgb = [1.0 / (1.0 + np.exp(-(self.head(vals, (L_ + 3) * D + c * (D // 2)) + self.aux[misc + 1 + c])))
                for c in range(3)]
         return np.stack(rgb + [sigma], axis=-1)
 
@@ -163,17 +169,17 @@ def test_blob_replays_to_reference_forward(golden_dir, tag, n_layers, d_hidden, 
     emu = Emu(blob, prec)
     assert emu.L == n_layers and emu.D == d_hidden
     assert emu.skip_mask == (0b10000 if n_layers > 5 else 0)
-    x, d = g["x"][:32], g["dirs"][:32]
+    x, d = g["x"][:16], g["dirs"][:16]
     ones_p, ones_d = np.ones(64), np.ones(32)
     y = emu.forward(x, d, ones_p, ones_d)
-    ref = g["y_full"][:32]
+    ref = g["y_full"][:16]
     # x3 modes: weights are hi+lo (16 / 22 mantissa bits), activations exact in this model;
     # single-pass modes: 8 / 11-bit weights
     tol = {0: 2e-5, 1: 2e-2, 2: 2e-6, 3: 3e-3}[prec]
     np.testing.assert_allclose(y[:, :3], ref[:, :3], rtol=0, atol=tol)
     np.testing.assert_allclose(y[:, 3], ref[:, 3], rtol=0, atol=tol)
     ys = emu.forward(x, None, ones_p, ones_d)
-    np.testing.assert_allclose(ys[:, 0], g["y_sigma"][:32, 0], rtol=0, atol=tol)
+    np.testing.assert_allclose(ys[:, 0], g["y_sigma"][:16, 0], rtol=0, atol=tol)
 
 
 def test_blob_frequency_mask_and_wide_variants(golden_dir):
@@ -183,8 +189,8 @@ def test_blob_frequency_mask_and_wide_variants(golden_dir):
     emu = Emu(blob, 0)
     assert emu.skip_mask == 0b1010
     gen = torch.Generator().manual_seed(3)
-    x = torch.rand(32, 3, generator=gen) * 2 - 1
-    d = torch.nn.functional.normalize(torch.randn(32, 3, generator=gen), dim=-1)
+    x = torch.rand(16, 3, generator=gen) * 2 - 1
+    d = torch.nn.functional.normalize(torch.randn(16, 3, generator=gen), dim=-1)
     pm, dm = O.freq_mask(3, 7, 0.6), O.freq_mask(3, 3, 0.5)
     ref = O.nerf_forward(sd, x.double(), d.double(), n_layers=6, skip=[1, 3], n_freqs=7, n_freqs_dir=3,
                          pos_mask=pm.double(), dir_mask=dm.double()).numpy()
