@@ -347,7 +347,17 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
         }
       }
     }
-    if (EPI == EPI_RELU_CVT || EPI == EPI_CVT || EPI == EPI_LAST_FULL) split_store<F16, X3>(v, out[tp < NOUT ? tp : 0]);
+    // The empty asm statements pin each pair's results here.  Without them LLVM sinks the pure conversion
+    // arithmetic to its first use (the next layer): all accumulator pairs of the layer then stay alive until
+    // its end (64 more registers) and the conversions run in one block after the last MFMA.
+    if (EPI == EPI_LAST_FULL || EPI == EPI_LAST_DENS) asm volatile("" : "+v"(heads.sigma));
+    if (EPI == EPI_RGB) asm volatile("" : "+v"(heads.rgb[0]), "+v"(heads.rgb[1]), "+v"(heads.rgb[2]));
+    if (EPI == EPI_RELU_CVT || EPI == EPI_CVT || EPI == EPI_LAST_FULL) {
+      Frag& o = out[tp < NOUT ? tp : 0];
+      split_store<F16, X3>(v, o);
+      if (X3) asm volatile("" : "+v"(o.hi), "+v"(o.lo));
+      else asm volatile("" : "+v"(o.hi));
+    }
   }
 }
 
