@@ -169,6 +169,8 @@ __global__ __launch_bounds__(kThreads) void k_mlp_fwd(MlpFwdArgs a) {
   const char* sbase = a.net.blob + a.net.stream_off;
   st.init(smem, nullptr, 0, 0, sbase, (uint32_t)(full ? a.net.nph_full : a.net.nph_density), 1);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  ARing ring;
+  prime_ring<PREC>(st, ring);
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t s = tile * 128 + wave * 16 + (lane & 15);
     const int64_t sc = s < a.n ? s : a.n - 1;
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(kThreads) void k_mlp_fwd(MlpFwdArgs a) {
     __builtin_amdgcn_wave_barrier();
     const TileSrc src{in_lds + (wave * 16 + (lane & 15)) * 6};
     float sigma, rgb[3] = {0.f, 0.f, 0.f};
-    mlp_tile<NT, PREC, FULL>(st, net, src, sigma, rgb);
+    mlp_tile<NT, PREC, FULL>(st, net, src, ring, sigma, rgb);
     if (lane < 16 && s < a.n) {
       if (full) {
         f32x4 o = {rgb[0], rgb[1], rgb[2], sigma};

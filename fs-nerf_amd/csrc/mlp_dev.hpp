@@ -263,9 +263,41 @@ __device__ __forceinline__ f32x4 mfma16(const s16x8& a, const s16x8& b, const f3
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+struct AFrag {  // A operand (weights) of one unit
+  s16x8 hi, lo;
+};
+// A operands are read from the LDS ring one k-step (two units) ahead of their MFMAs; the pair in flight
+// carries over from GEMM to GEMM, tile to tile and pass to pass: on entry to a GEMM `cur` holds its
+// units 0 and 1.
+struct ARing {
+  AFrag cur[2];
+};
+template <int PREC>
+__device__ __forceinline__ void load_afrag(const char* p, AFrag& f) {
+  f.hi = *reinterpret_cast<const s16x8*>(p);
+  if ((PREC & 1) == 0) f.lo = *reinterpret_cast<const s16x8*>(p + 1024);
+}
+template <int PREC>
+__device__ __forceinline__ void unit_mfma_r(const AFrag& a, const Frag& b, f32x4& acc) {
+  constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
+  acc = mfma16<F16>(a.hi, b.hi, acc);
+  if (X3) {
+    acc = mfma16<F16>(a.lo, b.hi, acc);
+    acc = mfma16<F16>(a.hi, b.lo, acc);
+  }
+}
+
 template <int PREC>
 __device__ __forceinline__ void unit_mfma(const char* ubase, const Frag& b, f32x4& acc) {
   constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
+#ifdef FSN_ABL_NOLDS  // timing experiment: operands from registers instead of the LDS ring
+  acc = mfma16<F16>(b.lo, b.hi, acc);
+  if (X3) {
+    acc = mfma16<F16>(b.hi, b.hi, acc);
+    acc = mfma16<F16>(b.lo, b.lo, acc);
+  }
+  return;
+#endif
   const s16x8 ah = *reinterpret_cast<const s16x8*>(ubase);
   acc = mfma16<F16>(ah, b.hi, acc);
   if (X3) {
@@ -289,8 +321,11 @@ __device__ __forceinline__ float relu_f32(float v) {  // on the sign bit: one v_
 //   EPI_RGB      : heads.rgb[c] += w_rgb[c] . relu(acc)                        (branch)
 template <int PREC, int NP_OUT, int KS_ACT, int KS_ENC, int EPI, int NACT, int NENC, int NOUT>
 __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int aux_bias, const Frag (&act)[NACT],
-                                           const Frag (&enc)[NENC], Frag (&out)[NOUT], Heads& heads, int g) {
+                                           const Frag (&enc)[NENC], Frag (&out)[NOUT], Heads& heads, ARing& ring,
+                                           int g) {
   constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
+  static_assert(kLead == 2, "the A-operand prefetch distance (one k-step = two units) equals the phase lead");
+  constexpr bool PREFETCH = !X3;
   constexpr int UPP = X3 ? 8 : 16;
   constexpr int UB = X3 ? 2048 : 1024;
   constexpr int KS = KS_ACT + KS_ENC;
@@ -303,18 +338,41 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
     f32x4 acc1 = *reinterpret_cast<const f32x4*>(bias + 32 * tp + 16 + 4 * g);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
-        const int u = (tp * KS + ks) * 2 + sub;  // compile-time after unrolling
-        // open the phase that starts kLead units from here (the one after this layer's last unit too)
-        if (((u + kLead) % UPP == 0 && u + kLead <= TOTAL && (kLead > 0 || u < TOTAL)) ||
-            (kLead > 0 && u + kLead == TOTAL && TOTAL % UPP != 0))
-          st.open_next();
+      const Frag& b = ks < KS_ACT ? act[ks < KS_ACT ? ks : 0] : enc[ks >= KS_ACT ? ks - KS_ACT : 0];
+      if constexpr (PREFETCH) {
+        const int u = (tp * KS + ks) * 2;  // first of this k-step's two units; compile-time after unrolling
+        // open the phase that starts two units from here (the one after this layer's last unit too)
+        if (((u + kLead) % UPP == 0 && u + kLead <= TOTAL) || (u + kLead == TOTAL && TOTAL % UPP != 0)) st.open_next();
         if (u % UPP == 0) st.enter_phase();
-        const char* ub = st.c_base + (u % UPP) * UB;
-        const Frag& b = ks < KS_ACT ? act[ks < KS_ACT ? ks : 0] : enc[ks >= KS_ACT ? ks - KS_ACT : 0];
-        if (sub == 0) unit_mfma<PREC>(ub, b, acc0);
-        else unit_mfma<PREC>(ub, b, acc1);
+        // A operands of the NEXT k-step (of the next GEMM / pass at the tail) are read from LDS in front of
+        // this k-step's MFMAs, one scheduling region per k-step so that hipcc cannot sink the reads back to
+        // their use.  Measured (bench_mlp, 8x256): single-pass modes 37.6 -> 42.4 % matrix-pipe busy; the
+        // x3 modes lose (55.2 -> 52.8 %: 32 more live registers tip the wide layers into scratch), so they
+        // keep the compiler's own read placement and rely on the partner wave of the SIMD.
+        AFrag nxt[2];
+        const int v = u + 2;
+        const char* src = (v < TOTAL) ? ((v / UPP == u / UPP) ? st.c_base : st.n_base) + (v % UPP) * UB
+                                      : st.n_base + (v - TOTAL) * UB;
+        load_afrag<PREC>(src, nxt[0]);
+        load_afrag<PREC>(src + UB, nxt[1]);
+        unit_mfma_r<PREC>(ring.cur[0], b, acc0);
+        unit_mfma_r<PREC>(ring.cur[1], b, acc1);
+        ring.cur[0] = nxt[0];
+        ring.cur[1] = nxt[1];
+        __builtin_amdgcn_sched_group_barrier(0x100, X3 ? 4 : 2, 0);  // DS reads
+        __builtin_amdgcn_sched_group_barrier(0x008, X3 ? 6 : 2, 0);  // MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+          const int u = (tp * KS + ks) * 2 + sub;  // compile-time after unrolling
+          // open the phase that starts kLead units from here (the one after this layer's last unit too)
+          if (((u + kLead) % UPP == 0 && u + kLead <= TOTAL) || (u + kLead == TOTAL && TOTAL % UPP != 0)) st.open_next();
+          if (u % UPP == 0) st.enter_phase();
+          const char* ub = st.c_base + (u % UPP) * UB;
+          if (sub == 0) unit_mfma<PREC>(ub, b, acc0);
+          else unit_mfma<PREC>(ub, b, acc1);
+        }
       }
     }
     // ---- epilogue of pair tp
@@ -354,11 +412,26 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
     if (EPI == EPI_RGB) asm volatile("" : "+v"(heads.rgb[0]), "+v"(heads.rgb[1]), "+v"(heads.rgb[2]));
     if (EPI == EPI_RELU_CVT || EPI == EPI_CVT || EPI == EPI_LAST_FULL) {
       Frag& o = out[tp < NOUT ? tp : 0];
+#ifdef FSN_ABL_NOCVT  // timing experiment: skip the fp32 -> hi/lo split
+      asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+      o = act[0];
+#else
       split_store<F16, X3>(v, o);
+#endif
       if (X3) asm volatile("" : "+v"(o.hi), "+v"(o.lo));
       else asm volatile("" : "+v"(o.hi));
     }
   }
+}
+
+// A-operand pair primed for the very first GEMM of a kernel (after WStream::init opened phase 0)
+template <int PREC>
+__device__ __forceinline__ void prime_ring(const WStream& st, ARing& ring) {
+  constexpr int UB = (PREC & 1) == 0 ? 2048 : 1024;
+  if ((PREC & 1) == 0) return;  // the x3 modes read their operands in place
+  load_afrag<PREC>(st.n_base, ring.cur[0]);
+  load_afrag<PREC>(st.n_base + UB, ring.cur[1]);
+  ring.cur[0].lo = ring.cur[1].lo = ring.cur[0].hi;
 }
 
 // ---------------------------------------------------------------- whole network, one tile
@@ -366,7 +439,7 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
 // l, l+16, l+32, l+48 hold the same sample).  The direction is read only in front of the branch
 // layer.  Outputs (valid in all lanes): sigma, and rgb when FULL.
 template <int NT, int PREC, bool FULL, class Src>
-__device__ __forceinline__ void mlp_tile(WStream& st, const NetDev& net, const Src& src, float& sigma,
+__device__ __forceinline__ void mlp_tile(WStream& st, const NetDev& net, const Src& src, ARing& ring, float& sigma,
                                          float (&rgb)[3]) {
   constexpr int NA = NT;  // k-steps of 32 across the hidden width
   constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
@@ -383,13 +456,13 @@ __device__ __forceinline__ void mlp_tile(WStream& st, const NetDev& net, const S
     src.pos(px, py, pz);
     encode<kKsPos, F16, X3>(px, py, pz, net.n_freqs_pos, misc + 4, net.pos_mask, g, pe);
   }
-  gemm_layer<PREC, NT, 0, kKsPos, EPI_RELU_CVT>(st, net, 0, none, pe, A, heads, g);
+  gemm_layer<PREC, NT, 0, kKsPos, EPI_RELU_CVT>(st, net, 0, none, pe, A, heads, ring, g);
 #define FSN_HIDDEN(EPI, IN, OUT, LIDX)                                                    \
   do {                                                                                    \
     if ((net.skip_mask >> ((LIDX)-1)) & 1u)                                               \
-      gemm_layer<PREC, NT, NA, kKsPos, EPI>(st, net, (LIDX)*D, IN, pe, OUT, heads, g);    \
+      gemm_layer<PREC, NT, NA, kKsPos, EPI>(st, net, (LIDX)*D, IN, pe, OUT, heads, ring, g);    \
     else                                                                                  \
-      gemm_layer<PREC, NT, NA, 0, EPI>(st, net, (LIDX)*D, IN, none, OUT, heads, g);       \
+      gemm_layer<PREC, NT, NA, 0, EPI>(st, net, (LIDX)*D, IN, none, OUT, heads, ring, g);       \
   } while (0)
   for (int l = 1; l <= L - 2; l += 2) {
     FSN_HIDDEN(EPI_RELU_CVT, A, B, l);
@@ -411,12 +484,12 @@ __device__ __forceinline__ void mlp_tile(WStream& st, const NetDev& net, const S
   }
   if (FULL) {
     // connection (no activation, models.py:130), then branch on [feat, dir_enc] (models.py:131-133)
-    gemm_layer<PREC, NT, NA, 0, EPI_CVT>(st, net, L * D, B, none, A, heads, g);
+    gemm_layer<PREC, NT, NA, 0, EPI_CVT>(st, net, L * D, B, none, A, heads, ring, g);
     Frag de[kKsDir];
     float dx, dy, dz;
     src.dir(dx, dy, dz);
     encode<kKsDir, F16, X3>(dx, dy, dz, net.n_freqs_dir, misc + 20, net.dir_mask, g, de);
-    gemm_layer<PREC, NT / 2, NA, kKsDir, EPI_RGB>(st, net, (L + 1) * D, A, de, B, heads, g);
+    gemm_layer<PREC, NT / 2, NA, kKsDir, EPI_RGB>(st, net, (L + 1) * D, A, de, B, heads, ring, g);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       float z = heads.rgb[c];

@@ -71,6 +71,8 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
   st.init(smem, k.netC.blob + k.netC.stream_off, hier ? (uint32_t)k.netC.nph_density : 0u, (uint32_t)k.nsubC,
           k.netF.blob + k.netF.stream_off, (uint32_t)k.netF.nph_full, (uint32_t)k.nsubF);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  ARing ring;
+  prime_ring<PREC>(st, ring);
   const int64_t R = a.R;
   const int64_t ngroups = (R + G - 1) / G;
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
         const int g = idc / S, i = idc - g * S;
         const RaySrc src{S_.rays + 6 * g, S_.edgesC + g * (S + 1) + i};
         float sigma, rgb[3];
-        mlp_tile<NT, PREC, false>(st, netC, src, sigma, rgb);
+        mlp_tile<NT, PREC, false>(st, netC, src, ring, sigma, rgb);
         if (lane < 16 && idx < G * S) S_.sigC[idx] = sigma;
       }
       lds_barrier();
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
       const int g = idc / So, i = idc - g * So;
       const RaySrc src{S_.rays + 6 * g, edges + g * (So + 1) + i};
       float sigma, rgb[3];
-      mlp_tile<NT, PREC, true>(st, netF, src, sigma, rgb);
+      mlp_tile<NT, PREC, true>(st, netF, src, ring, sigma, rgb);
       if (lane < 16 && idx < G * So) {
         S_.sigF[idx] = sigma;
         S_.rgbF[3 * idx + 0] = rgb[0];
