@@ -54,6 +54,8 @@ SIGNATURES = {
     "fsn_mlp_pack_host": (_i, [_PD, _i, _vp, _vp, _vp]),
     "fsn_mlp_fwd": (_i, [_PD, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "fsn_render_rays_fused": (_i, [_PD, _i, _vp, _vp, C.POINTER(RenderArgs), _vp]),
+    "fsn_occlusion_reg_fwd": (_i, [_vp, _vp, _vp, _i64, _i64, _f, _f, _i, _vp, _vp, _vp]),
+    "fsn_to8b": (_i, [_vp, _i64, _vp, _vp]),
 }
 
 _lib = None

@@ -164,6 +164,53 @@ __global__ void k_composite_packed(const float* __restrict__ sig, const float* _
   composite_ray(sig + b, rgb + 3 * b, t0 + b, t1 + b, (int)(e - b), bk.has != 0, bk.c[0], bk.c[1], bk.c[2], o);
 }
 
+// ---------------------------------------------------------------- "next" rows
+// OcclusionRegularizer (src/core/loss.py:26-60): one wavefront per ray sums w(t) sigma over the ray's
+// samples (range found like in k_composite_packed); a second, single-block kernel averages the sums of the
+// non-empty rays in a fixed order (deterministic, no float atomics).
+__global__ void k_occl_ray_sums(const float* __restrict__ sig, const float* __restrict__ t,
+                                const int64_t* __restrict__ ri, int64_t N, int64_t R, float a, float b, int func,
+                                float* __restrict__ sums) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+  if (r >= R) return;
+  const int64_t lo = lower_bound_i64(ri, N, r), hi = lower_bound_i64(ri, N, r + 1);
+  float acc = 0.f;
+  for (int64_t i = lo + lane; i < hi; i += 64) {
+    const float w = func == 0 ? (-a * t[i] + b) : (a * expf(-b * t[i]));
+    acc += w * sig[i];
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) sums[r] = (hi > lo) ? acc : __builtin_nanf("");  // NaN marks "no samples"
+}
+
+__global__ void k_occl_mean(const float* __restrict__ sums, int64_t R, float* __restrict__ out) {
+  __shared__ float s_sum[256];
+  __shared__ int s_cnt[256];
+  float acc = 0.f;
+  int cnt = 0;
+  for (int64_t r = threadIdx.x; r < R; r += 256) {
+    const float v = sums[r];
+    if (v == v) { acc += v; ++cnt; }
+  }
+  s_sum[threadIdx.x] = acc;
+  s_cnt[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) { s_sum[threadIdx.x] += s_sum[threadIdx.x + k]; s_cnt[threadIdx.x] += s_cnt[threadIdx.x + k]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = s_sum[0] / (float)s_cnt[0];  // 0/0 = NaN like torch.mean of an empty stack
+}
+
+// to8b (src/render/rendering.py:21): (255 * clip(x,0,1)).astype(uint8) - truncation, like numpy
+__global__ void k_to8b(const float* __restrict__ x, int64_t n, uint8_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = 255.0f * fminf(fmaxf(x[i], 0.0f), 1.0f);
+  out[i] = (uint8_t)v;
+}
+
 static inline unsigned nblocks(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
 }  // namespace fsn
@@ -279,5 +326,30 @@ extern "C" int fsn_composite_packed_fwd(const float* sigmas, const float* rgbs, 
                                                                   make_bkgd(bkgd_host), colors, opacity, depth,
                                                                   weights, alphas, trans);
   FSN_LAUNCH_CHECK("k_composite_packed");
+  return FSN_OK;
+}
+
+extern "C" int fsn_occlusion_reg_fwd(const float* sigmas, const float* t_vals, const int64_t* ray_idxs, int64_t N,
+                                     int64_t n_rays, float a, float b, int func, float* ray_sums, float* out,
+                                     fsn_stream_t stream) {
+  FSN_REQUIRE(N >= 0 && n_rays >= 0 && (func == 0 || func == 1), FSN_E_INVALID, "fsn_occlusion_reg_fwd: bad arguments");
+  FSN_REQUIRE(out && (n_rays == 0 || ray_sums), FSN_E_INVALID, "fsn_occlusion_reg_fwd: null output");
+  FSN_REQUIRE(N == 0 || (sigmas && t_vals && ray_idxs), FSN_E_INVALID, "fsn_occlusion_reg_fwd: null input");
+  if (n_rays > 0) {
+    k_occl_ray_sums<<<nblocks(n_rays, 4), 256, 0, as_stream(stream)>>>(sigmas, t_vals, ray_idxs, N, n_rays, a, b, func,
+                                                                     ray_sums);
+    FSN_LAUNCH_CHECK("k_occl_ray_sums");
+  }
+  k_occl_mean<<<1, 256, 0, as_stream(stream)>>>(ray_sums, n_rays, out);
+  FSN_LAUNCH_CHECK("k_occl_mean");
+  return FSN_OK;
+}
+
+extern "C" int fsn_to8b(const float* x, int64_t n, uint8_t* out, fsn_stream_t stream) {
+  FSN_REQUIRE(n >= 0, FSN_E_INVALID, "fsn_to8b: bad size");
+  if (n == 0) return FSN_OK;
+  FSN_REQUIRE(x && out, FSN_E_INVALID, "fsn_to8b: null pointer");
+  k_to8b<<<nblocks(n, 256), 256, 0, as_stream(stream)>>>(x, n, out);
+  FSN_LAUNCH_CHECK("k_to8b");
   return FSN_OK;
 }

@@ -278,3 +278,34 @@ def render_fused(pm_coarse: Optional[PackedMLP], pm_fine: PackedMLP, rays_o: Ten
                                               _p(pm_coarse.blob) if pm_coarse is not None else None,
                                               _p(pm_fine.blob), C.byref(a), _stream()), "fsn_render_rays_fused")
     return colors, opacity, depth, ex
+
+
+# ------------------------------------------------------------------ "next" rows
+def occlusion_reg(sigmas: Tensor, t_vals: Tensor, ray_idxs: Tensor, a: float, b: float, func: str = "linear",
+                  n_rays: Optional[int] = None) -> Tensor:
+    """OcclusionRegularizer forward (src/core/loss.py:26-60) -> 0-dim tensor."""
+    sig, t = _f32(sigmas, "sigmas").reshape(-1), _f32(t_vals, "t_vals").reshape(-1)
+    ri = ray_idxs.contiguous()
+    if ri.dtype != torch.int64:
+        ri = ri.long()
+    N = sig.numel()
+    if n_rays is None:
+        n_rays = int(ri[-1].item()) + 1 if N > 0 else 0
+    if func not in ("linear", "exp"):
+        raise ValueError(f"Unknown occlusion regularizer type: {func}")
+    sums = torch.empty(max(n_rays, 1), device=sig.device, dtype=torch.float32)
+    out = torch.empty(1, device=sig.device, dtype=torch.float32)
+    with torch.cuda.device(sig.device):
+        L.check(L.lib().fsn_occlusion_reg_fwd(_p(sig), _p(t), _p(ri), N, n_rays, float(a), float(b),
+                                              0 if func == "linear" else 1, _p(sums), _p(out), _stream()),
+                "fsn_occlusion_reg_fwd")
+    return out.reshape(())
+
+
+def to8b(x: Tensor) -> Tensor:
+    """(255 * clip(x, 0, 1)).astype(uint8) on the device (src/render/rendering.py:21)."""
+    x = _f32(x, "x")
+    out = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+    with torch.cuda.device(x.device):
+        L.check(L.lib().fsn_to8b(_p(x), x.numel(), _p(out), _stream()), "fsn_to8b")
+    return out

@@ -16,6 +16,7 @@ compositor kernels with the model evaluated in between, exactly like the referen
 """
 from typing import Callable, Optional, Tuple
 
+import numpy as np
 import torch
 from torch import Tensor, nn
 
@@ -169,3 +170,28 @@ def render_frame(hwf: Tuple[int, int, float], near: float, far: float, pose: Ten
     img = torch.cat(img, dim=0)
     depth = torch.cat(depth_map, dim=0).clamp(near, far)
     return img.reshape(H, W, 3), depth.reshape(H, W)
+
+
+def to8b(x):
+    """float image(s) in [0,1] -> uint8 (rendering.py:21).  Tensors are converted on the GPU."""
+    if isinstance(x, Tensor):
+        return ops.to8b(x)
+    return (255 * np.clip(x, 0, 1)).astype(np.uint8)
+
+
+def render_path(render_poses: Tensor, hwf: Tuple[int, int, float], near: float, far: float, chunksize: int,
+                model: nn.Module, estimator, ndc: bool = False, train: bool = False, white_bkgd: bool = False,
+                render_step_size: float = 5e-3, device: torch.device = torch.device("cuda"), *,
+                model_fine: Optional[nn.Module] = None):
+    """One frame per pose under no_grad -> (frames [N,H,W,3], d_frames [N,H,W]) as numpy arrays, like the
+    reference (rendering.py:180-248; no progress bar).  Each frame is get_rays + one fused launch per chunk."""
+    H, W, _ = hwf
+    frames, d_frames = [], []
+    for pose in render_poses:
+        with torch.no_grad():
+            rgb, depth = render_frame(hwf, near, far, pose, chunksize, estimator, model, train=train, ndc=ndc,
+                                      white_bkgd=white_bkgd, render_step_size=render_step_size, device=device,
+                                      model_fine=model_fine)
+        frames.append(rgb.reshape(H, W, 3).detach().cpu().numpy())
+        d_frames.append(depth.reshape(H, W).detach().cpu().numpy())
+    return np.stack(frames, 0), np.stack(d_frames, 0)

@@ -162,6 +162,19 @@ int fsn_render_rays_fused(const fsn_mlp_desc* desc, int prec, const void* blob_c
                           const void* blob_fine, const fsn_render_args* args_host,
                           fsn_stream_t stream);
 
+/* ---- "next" rows ------------------------------------------------------------------ */
+
+/* f4: OcclusionRegularizer.__call__(sigmas, t_vals, ray_idxs)          src/core/loss.py:26-60
+ * mean over the rays that own at least one sample of  sum_i w(t_i) sigma_i,  w = -a t + b (func 0,
+ * 'linear') or a exp(-b t) (func 1, 'exp').  ray_idxs int64 [N] non-decreasing, n_rays > max index.
+ * ray_sums [n_rays] is caller-provided workspace; out is one float. */
+int fsn_occlusion_reg_fwd(const float* sigmas, const float* t_vals, const int64_t* ray_idxs, int64_t N,
+                          int64_t n_rays, float a, float b, int func, float* ray_sums, float* out,
+                          fsn_stream_t stream);
+
+/* f3: to8b(x) = (255 * clip(x, 0, 1)).astype(uint8)                    src/render/rendering.py:21 */
+int fsn_to8b(const float* x, int64_t n, uint8_t* out, fsn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,73 @@
+"""SURVEY.md 8f "next" rows built so far: occlusion regulariser (f4), lr schedules (f1), to8b / render_path
+(f3).  Expected values come from the reference itself (tests/golden/g5_next.npz, made by make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fs_nerf_amd  # noqa: F401
+from oracle import fsnerf_oracle as O
+
+
+def test_scheduler_matches_reference_golden(golden_dir):
+    from fs_nerf_amd.core.scheduler import Constant, ExponentialDecay
+    g = np.load(os.path.join(golden_dir, "g5_next.npz"))
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=5e-4)
+    sch = ExponentialDecay(opt, 8000, 5e-4, r=0.1)
+    for t, want in zip(g["sched_t"], g["sched_lr"]):
+        sch.t = int(t)
+        assert sch.lr == pytest.approx(float(want), rel=1e-12)
+    sch.t = 0
+    sch.step()
+    assert opt.param_groups[0]["lr"] == sch.lr and sch.t == 1
+    assert Constant(opt, 10, 3e-4).lr == 3e-4
+    with pytest.raises(ValueError):
+        Constant(opt, 10, -1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("func", ["linear", "exp"])
+def test_occlusion_regularizer_golden_and_large(golden_dir, func):
+    from fs_nerf_amd.core.loss import OcclusionRegularizer
+    dev = torch.device("cuda:0")
+    g = np.load(os.path.join(golden_dir, "g5_next.npz"))
+    reg = OcclusionRegularizer(0.5, 3.0, func)
+    got = reg(torch.from_numpy(g["occ_sigmas"]).to(dev), torch.from_numpy(g["occ_t"]).to(dev),
+              torch.from_numpy(g["occ_ray_idx"]).to(dev))
+    assert got.shape == ()
+    np.testing.assert_allclose(float(got), float(g["occ_" + func]), rtol=1e-5)
+    # a packed batch of the fused renderer: 4096 rays x 192 samples, against the formula in float64
+    gen = torch.Generator().manual_seed(0)
+    R, S = 4096, 192
+    ri = torch.arange(R).repeat_interleave(S)
+    sig, t = torch.rand(R * S, generator=gen) * 5, torch.rand(R * S, generator=gen) * 4 + 2
+    w = (-0.5 * t.double() + 3.0) if func == "linear" else 0.5 * torch.exp(-3.0 * t.double())
+    want = (w * sig.double()).reshape(R, S).sum(-1).mean()
+    got = reg(sig.to(dev), t.to(dev), ri.to(dev))
+    np.testing.assert_allclose(float(got), float(want), rtol=1e-5)
+    with pytest.raises(ValueError):
+        OcclusionRegularizer(0.5, 3.0, "cubic")(sig.to(dev), t.to(dev), ri.to(dev))
+
+
+@pytest.mark.gpu
+def test_to8b_and_render_path(golden_dir):
+    from fs_nerf_amd.core.models import NeRF
+    from fs_nerf_amd.render import rendering as Rm
+    dev = torch.device("cuda:0")
+    x = torch.tensor([-0.5, 0.0, 0.2, 0.999, 1.0, 1.7, 127.5 / 255, 128 / 255], device=dev)
+    want = (255 * np.clip(x.cpu().numpy(), 0, 1)).astype(np.uint8)
+    assert Rm.to8b(x).cpu().numpy().tolist() == want.tolist()
+    assert Rm.to8b(x.cpu().numpy()).tolist() == want.tolist()
+    torch.manual_seed(1)
+    m = NeRF(3, 3, 4, 128, (4,), pos_fn={"n_freqs": 10, "log_space": True},
+             dir_fn={"n_freqs": 4, "log_space": True}).to(dev).eval()
+    est = Rm.StratifiedEstimator(2.0, 6.0, 64, 128)
+    poses = torch.stack([O.pose_from_spherical(4.0311289, 50.0, phi) for phi in (0.0, 120.0)])
+    hwf = (20, 24, 30.0)
+    frames, d_frames = Rm.render_path(poses, hwf, 2.0, 6.0, 200, m, est, white_bkgd=True, device=dev)
+    assert frames.shape == (2, 20, 24, 3) and d_frames.shape == (2, 20, 24) and frames.dtype == np.float32
+    img, dep = Rm.render_frame(hwf, 2.0, 6.0, poses[1], 480, est, m, white_bkgd=True, device=dev)
+    np.testing.assert_array_equal(frames[1], img.cpu().numpy())
+    np.testing.assert_array_equal(d_frames[1], dep.cpu().numpy())
