@@ -24,6 +24,9 @@ struct RenderKArgs {
 };
 
 struct RenderLds {
+  // The launch arguments live in LDS, not in SGPRs: they are read where they are used (mostly between the
+  // MLP passes) instead of being held - and spilled - across the register-starved MFMA passes.
+  fsn_render_args args;
   float rays[kMaxG * 6];
   float edgesC[kMaxGroupSamples + kMaxG];
   float sigC[kMaxGroupSamples];
@@ -59,7 +62,9 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
   float* auxC = reinterpret_cast<float*>(smem + kRingBytes);
   float* auxF = reinterpret_cast<float*>(smem + kRingBytes + kNetLdsBytes);
   RenderLds& S_ = *reinterpret_cast<RenderLds*>(smem + kRingBytes + 2 * kNetLdsBytes);
-  const fsn_render_args& a = k.a;
+  if (threadIdx.x == 0) S_.args = k.a;
+  __syncthreads();
+  const fsn_render_args& a = S_.args;
   const int S = a.S, NI = a.n_imp, So = S + NI, G = k.G;
   const bool hier = NI > 0;
   NetDev netC, netF;
