@@ -116,12 +116,17 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     assert torch.cuda.is_available(), "bench.py needs the GPU (no CPU fallback)"
+    local = local % max(torch.cuda.device_count(), 1)  # (rehearsals put several ranks on one card)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
+    backend = os.environ.get("FSN_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; "gloo" for rehearsals
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from fs_nerf_amd import ops
     from fs_nerf_amd.render import rendering as Rm
@@ -163,7 +168,7 @@ def main():
     dt = time.perf_counter() - t0
     assert bool(torch.isfinite(out[0]).all())
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
