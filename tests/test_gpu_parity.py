@@ -408,3 +408,65 @@ def test_render_frame_and_properties(dev, golden_dir):
     (rgb, op, _, ex), _, _ = out
     close(ex["weights"].reshape(5000, 192).sum(-1, keepdim=True), op, atol=1e-5, what="opacity = sum weights")
     assert torch.equal(rgb, img.reshape(-1, 3)[:5000])
+
+
+# ------------------------------------------------------------------ BASELINE.json configs 2, 4, 5 (shapes)
+def test_config2_freq_mask_on_coarse_only(dev, golden_dir):
+    """configs[1]: 400x400-style rays, 64 coarse samples, 8x256 MLP, frequency mask on (ratio 0.5)."""
+    from fs_nerf_amd.render import rendering as Rm
+    _, sd = load_sd(golden_dir, "8x256")
+    m = make_model(sd, 8, 256, [4], dev)
+    pm, dm = O.freq_mask(3, 10, 0.5), O.freq_mask(3, 4, 0.5)
+    m.set_freq_mask(pm, dm)
+    o, d, gen = _rays(300, 11, hw=400, focal=555.5555)
+    est = Rm.StratifiedEstimator(2.0, 6.0, 64, 0)
+    out = Rm.render_rays(o, d, est, m, white_bkgd=False, device=dev)
+    want = O.render_rays_oracle(o, d, sd, None, CFG["8x256"], near=2.0, far=6.0, n_samples=64, white_bkgd=False,
+                                pos_mask=pm, dir_mask=dm, edges_override=out[0][3]["edges"].cpu())
+    _check_render(out, want, "config 2 (mask on)")
+    m.set_freq_mask(None, None)
+    out2 = Rm.render_rays(o, d, est, m, white_bkgd=False, device=dev)
+    assert float((out2[0][0] - out[0][0]).abs().max()) > 1e-3, "the mask must change the image"
+
+
+def test_config4_ndc_forward_facing(dev, golden_dir):
+    """configs[3] geometry (inference part): LLFF-style forward-facing rays through to_ndc(near=1), near 0 / far 1,
+    64+128 samples (llff.py:51-53,75-76).  NDC directions are not unit length."""
+    from fs_nerf_amd.render import rendering as Rm
+    from fs_nerf_amd.utils import utilities as U
+    _, sd = load_sd(golden_dir, "8x256")
+    m = make_model(sd, 8, 256, [4], dev)
+    hwf = (378, 504, 407.6)
+    pose = torch.eye(4)
+    pose[:3, 3] = torch.tensor([0.1, -0.05, 0.0])
+    o, d = U.get_rays(pose, hwf, dev)
+    no, nd = U.to_ndc(o.reshape(-1, 3), d.reshape(-1, 3), hwf, 1.0)
+    idx = torch.randperm(378 * 504, generator=torch.Generator().manual_seed(0))[:200].to(dev)
+    no, nd = no[idx].contiguous(), nd[idx].contiguous()
+    est = Rm.StratifiedEstimator(0.0, 1.0, 64, 128)
+    out = Rm.render_rays(no, nd, est, m, white_bkgd=True, device=dev)
+    want = O.render_rays_oracle(no.cpu(), nd.cpu(), sd, None, CFG["8x256"], near=0.0, far=1.0, n_samples=64,
+                                n_importance=128, white_bkgd=True, edges_override=out[0][3]["edges"].cpu())
+    _check_render(out, want, "config 4 (ndc)")
+
+
+def test_config5_bf16_128_256(dev, golden_dir):
+    """configs[4] shape: 128+256 samples, bf16 weights/activations (single MFMA pass).  Tolerance relaxed and
+    stated: |rgb - fp32 oracle| <= 3e-2 on the kernel's own sample set (bf16 has 8 mantissa bits)."""
+    from fs_nerf_amd.render import rendering as Rm
+    _, sd = load_sd(golden_dir, "8x256")
+    m = make_model(sd, 8, 256, [4], dev, precision="bf16")
+    o, d, gen = _rays(96, 5, hw=1600, focal=2222.2)
+    est = Rm.StratifiedEstimator(2.0, 6.0, 128, 256)
+    out = Rm.render_rays(o, d, est, m, white_bkgd=True, device=dev)
+    (rgb, op, dep, ex), ri, tv = out
+    assert ex["weights"].shape == (96 * 384,) and ex["edges"].shape == (96, 385)
+    want = O.render_rays_oracle(o, d, sd, None, CFG["8x256"], near=2.0, far=6.0, n_samples=128, n_importance=256,
+                                white_bkgd=True, edges_override=ex["edges"].cpu())
+    close(rgb, want[0][0], rtol=0, atol=3e-2, what="bf16 rgb_map")
+    close(op, want[0][1], rtol=0, atol=3e-2, what="bf16 opacity")
+    m16 = make_model(sd, 8, 256, [4], dev, precision="fp16")
+    out16 = Rm.render_rays(o, d, est, m16, white_bkgd=True, device=dev)
+    want16 = O.render_rays_oracle(o, d, sd, None, CFG["8x256"], near=2.0, far=6.0, n_samples=128, n_importance=256,
+                                  white_bkgd=True, edges_override=out16[0][3]["edges"].cpu())
+    close(out16[0][0], want16[0][0], rtol=0, atol=5e-3, what="fp16 rgb_map")
