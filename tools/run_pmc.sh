@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect rocprofv3 PMC passes for the bench workload (run ON the GPU box via gpurun).
-# usage: bash profiles_run_pmc.sh <tag> [bench args...]
+# usage: bash tools/run_pmc.sh <tag> [bench args...]
 set -e
 TAG=${1:-r01}; shift || true
 R=${GRAFT_REPO_ROOT:-/root/repo}

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise the rocprofv3 PMC passes collected by profiles_run_pmc.sh into profiles/<tag>_pmc_summary.json
+"""Summarise the rocprofv3 PMC passes collected by tools/run_pmc.sh into profiles/<tag>_pmc_summary.json
 (+ a copy of the per-kernel rows).  usage: python tools/summarize_pmc.py <tag> [kernel-substring]"""
 import csv
 import glob
