@@ -7,7 +7,8 @@ Parameters are ordinary nn.Linear modules under the reference's attribute names,
 `state_dict()` loads unchanged (keys layers.N.*, sigma.*, connection.*, branch.*, rgb.*).
 `forward` never touches them with torch ops: they are packed into the MFMA streaming layout
 (re-packed whenever a parameter's version counter changes) and the whole network runs in the
-fused kernel `fsn_mlp_fwd`.  Additions over the reference: an optional frequency mask
+fused kernel `fsn_mlp_fwd`.  In training mode with autograd enabled, `forward(x, dirs)` runs the
+first-version training path instead (`_NerfTrainFn`: fp32 activations kept, library GEMMs).  Additions over the reference: an optional frequency mask
 (`set_freq_mask`) and the arithmetic mode (`precision`: "bf16x3" ~fp32 accuracy, "bf16" fast).
 """
 from typing import Optional, Sequence, Tuple
@@ -35,6 +36,33 @@ class PositionalEncoder(nn.Module):
 
     def forward(self, x: Tensor, mask: Optional[Tensor] = None) -> Tensor:
         return ops.posenc(x, self.freqs, mask)
+
+
+class _NerfTrainFn(torch.autograd.Function):
+    """NeRF.forward with gradients (first version): fp32 activations are kept for the
+    backward, Linear layers run as fp32 library GEMMs (`fsn_nerf_train_fwd/_bwd`).  Gradients flow to the
+    parameters only (sample positions / directions need none on this path)."""
+
+    @staticmethod
+    def forward(ctx, model, x, dirs, *params):
+        n = len(params) // 2
+        weights, biases = params[:n], params[n:]
+        desc = ops.make_desc(model.n_layers, model.d_hidden, model.skip, model.pos_encoder.freqs,
+                             model.dir_encoder.freqs)
+        dev = x.device
+        out, work = ops.nerf_train_fwd(desc, weights, biases, x, dirs, model._mask(model.pos_mask, dev),
+                                       model._mask(model.dir_mask, dev))
+        ctx.desc, ctx.work, ctx.out = desc, work, out
+        ctx.weights = [w.detach() for w in weights]
+        ctx.lead = x.shape[:-1]
+        return out.reshape(*x.shape[:-1], 4)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        dW, db = ops.nerf_train_bwd(ctx.desc, ctx.weights, ctx.work, ctx.out, d_out.contiguous())
+        ctx.work = None
+        db = [g.reshape(-1) for g in db]
+        return (None, None, None, *dW, *db)
 
 
 class NeRF(nn.Module):
@@ -95,8 +123,11 @@ class NeRF(nn.Module):
     # -- reference surface ---------------------------------------------------------
     def forward(self, x: Tensor, dirs: Optional[Tensor] = None) -> Tensor:
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                "NeRF.forward: the backward kernels are not built yet (SURVEY.md 8 f1); call under "
-                "torch.no_grad() or model.eval() - there is no PyTorch fallback by design")
+            if dirs is None:
+                raise NotImplementedError(
+                    "NeRF.forward(x) with gradients: the density-only pass has no backward (the reference runs it "
+                    "under torch.no_grad(), rendering.py:58-64); call it under torch.no_grad()")
+            ws, bs = self._tensors()
+            return _NerfTrainFn.apply(self, x, dirs, *ws, *bs)
         dev = x.device
         return ops.mlp_fwd(self.packed(), x, dirs, self._mask(self.pos_mask, dev), self._mask(self.dir_mask, dev))

@@ -309,3 +309,55 @@ def to8b(x: Tensor) -> Tensor:
     with torch.cuda.device(x.device):
         L.check(L.lib().fsn_to8b(_p(x), x.numel(), _p(out), _stream()), "fsn_to8b")
     return out
+
+
+# ------------------------------------------------------------------ training step
+def _ptr_array(ts: Sequence[Tensor]):
+    return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def nerf_train_fwd(desc: L.MlpDesc, weights: Sequence[Tensor], biases: Sequence[Tensor], x: Tensor, dirs: Tensor,
+                   pos_mask: Optional[Tensor], dir_mask: Optional[Tensor]):
+    """NeRF.forward keeping fp32 activations for the backward: -> (out [n,4], workspace)."""
+    x, d = _f32(x, "x").reshape(-1, 3), _f32(dirs, "dirs").reshape(-1, 3)
+    n = x.shape[0]
+    ws_ = [_f32(w.detach(), "weight") for w in weights]
+    bs_ = [_f32(b.detach(), "bias") for b in biases]
+    nfl = L.lib().fsn_nerf_train_workspace_floats(C.byref(desc), n)
+    if nfl < 0:
+        L.check(int(nfl), "fsn_nerf_train_workspace_floats")
+    work = torch.empty(max(int(nfl), 1), device=x.device, dtype=torch.float32)
+    out = torch.empty(n, 4, device=x.device, dtype=torch.float32)
+    pm = None if pos_mask is None else _f32(pos_mask, "pos_mask")
+    dm = None if dir_mask is None else _f32(dir_mask, "dir_mask")
+    with torch.cuda.device(x.device):
+        L.check(L.lib().fsn_nerf_train_fwd(C.byref(desc), _ptr_array(ws_), _ptr_array(bs_), _p(x), _p(d), _p(pm), _p(dm),
+                                           n, _p(work), _p(out), _stream()), "fsn_nerf_train_fwd")
+    return out, work
+
+
+def nerf_train_bwd(desc: L.MlpDesc, weights: Sequence[Tensor], work: Tensor, out: Tensor, d_out: Tensor):
+    """-> (d_weights, d_biases) lists in state_dict order."""
+    ws_ = [_f32(w.detach(), "weight") for w in weights]
+    d_out = _f32(d_out, "d_out").reshape(-1, 4)
+    n = d_out.shape[0]
+    dW = [torch.empty_like(w) for w in ws_]
+    db = [torch.empty(w.shape[0], device=w.device, dtype=torch.float32) for w in ws_]
+    with torch.cuda.device(work.device):
+        L.check(L.lib().fsn_nerf_train_bwd(C.byref(desc), _ptr_array(ws_), n, _p(work), _p(out), _p(d_out),
+                                           _ptr_array(dW), _ptr_array(db), _stream()), "fsn_nerf_train_bwd")
+    return dW, db
+
+
+def composite_packed_bwd(sigmas, rgbs, t_starts, t_ends, ray_indices, n_rays, bkgd, d_colors, d_opacity):
+    sig, rgb = _f32(sigmas, "sigmas"), _f32(rgbs, "rgbs")
+    t0, t1 = _f32(t_starts, "t_starts"), _f32(t_ends, "t_ends")
+    ri = ray_indices.contiguous()
+    N = sig.numel()
+    dc = _f32(d_colors, "d_colors")
+    dop = None if d_opacity is None else _f32(d_opacity, "d_opacity").reshape(-1)
+    ds, dr = torch.empty_like(sig), torch.empty_like(rgb)
+    with torch.cuda.device(sig.device):
+        L.check(L.lib().fsn_composite_packed_bwd(_p(sig), _p(rgb), _p(t0), _p(t1), _p(ri), N, n_rays, _bk(bkgd), _p(dc),
+                                                 _p(dop), _p(ds), _p(dr), _stream()), "fsn_composite_packed_bwd")
+    return ds, dr

@@ -73,13 +73,38 @@ class StratifiedEstimator(nn.Module):
         return None
 
 
+class _CompositeFn(torch.autograd.Function):
+    """Volume integration with gradients to sigmas and rgbs (training step)."""
+
+    @staticmethod
+    def forward(ctx, sigmas, rgbs, t_starts, t_ends, ray_indices, n_rays, bkgd):
+        colors, opacity, depth, ex = ops.composite_packed(sigmas, rgbs, t_starts, t_ends, ray_indices, n_rays, bkgd)
+        ctx.save_for_backward(ex["sigmas"], ex["rgbs"], t_starts, t_ends, ray_indices)
+        ctx.n_rays, ctx.bkgd = n_rays, bkgd
+        ctx.mark_non_differentiable(depth, ex["weights"], ex["alphas"], ex["trans"])
+        return colors, opacity, depth, ex["weights"], ex["alphas"], ex["trans"]
+
+    @staticmethod
+    def backward(ctx, d_colors, d_opacity, *_):
+        sig, rgb, t0, t1, ri = ctx.saved_tensors
+        ds, dr = ops.composite_packed_bwd(sig, rgb, t0, t1, ri, ctx.n_rays, ctx.bkgd, d_colors.contiguous(),
+                                          None if d_opacity is None else d_opacity.contiguous())
+        return ds.reshape(sig.shape), dr.reshape(rgb.shape), None, None, None, None, None
+
+
 def rendering(t_starts: Tensor, t_ends: Tensor, ray_indices: Tensor, n_rays: int,
               rgb_sigma_fn: Callable, render_bkgd: Optional[Tensor] = None):
     """nerfacc.volrend.rendering's contract: -> (colors [n_rays,3], opacities [n_rays,1],
-    depths [n_rays,1], extras).  AssertionError on the same shape violations."""
+    depths [n_rays,1], extras).  AssertionError on the same shape violations.  Differentiable with
+    respect to the rgbs / sigmas returned by `rgb_sigma_fn` (depth carries no gradient)."""
     rgbs, sigmas = rgb_sigma_fn(t_starts, t_ends, ray_indices)
     assert rgbs.shape[-1] == 3, "rgbs must have 3 channels, got {}".format(rgbs.shape)
     assert sigmas.shape == t_starts.shape, "sigmas must have shape of (N,)! Got {}".format(sigmas.shape)
+    if torch.is_grad_enabled() and (rgbs.requires_grad or sigmas.requires_grad):
+        bk = None if render_bkgd is None else [float(v) for v in render_bkgd.detach().cpu().tolist()]
+        colors, opacity, depth, w, a, tr = _CompositeFn.apply(sigmas, rgbs.contiguous(), t_starts, t_ends,
+                                                             ray_indices, n_rays, bk)
+        return colors, opacity, depth, {"weights": w, "alphas": a, "trans": tr, "sigmas": sigmas, "rgbs": rgbs}
     return ops.composite_packed(sigmas, rgbs, t_starts, t_ends, ray_indices, n_rays, render_bkgd)
 
 
@@ -94,8 +119,13 @@ def render_rays(rays_o: Tensor, rays_d: Tensor, estimator, model: nn.Module, tra
     rays_d = rays_d.to(device)
     bk = float(white_bkgd)
 
+    fine_model = model_fine if model_fine is not None else model
+    needs_grad = torch.is_grad_enabled() and isinstance(fine_model, nn.Module) and fine_model.training and \
+        any(p.requires_grad for p in fine_model.parameters())
+    # the fused launch is forward-only; a training step goes through sampler -> model(x, d) -> rendering,
+    # each differentiable where the reference's is
     fused = isinstance(estimator, StratifiedEstimator) and isinstance(model, NeRF) and \
-        (model_fine is None or isinstance(model_fine, NeRF))
+        (model_fine is None or isinstance(model_fine, NeRF)) and not needs_grad
     if fused:
         R = rays_o.shape[0]
         fine = model_fine if model_fine is not None else model

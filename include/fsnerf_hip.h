@@ -172,6 +172,28 @@ int fsn_occlusion_reg_fwd(const float* sigmas, const float* t_vals, const int64_
                           int64_t n_rays, float a, float b, int func, float* ray_sums, float* out,
                           fsn_stream_t stream);
 
+/* f1 (first version): the training step around the path.        src/run-nerf.py:243-285, models.py:111-143
+ * "Plain" formulation: fp32 activations are kept in a caller-provided workspace, the Linear layers are
+ * library GEMMs (rocBLAS sgemm, bound with dlopen at first use), everything else HIP kernels.  Exact fp32
+ * gradients; the rendering path does not use these entry points.
+ *   weights / biases / d_weights / d_biases: HOST arrays of n_layers+4 DEVICE pointers in state_dict order
+ *   (layers.0.., sigma, connection, branch, rgb); gradients are overwritten, not accumulated.
+ *   workspace: fsn_nerf_train_workspace_floats(desc, n) floats, written by _fwd, consumed (and scribbled on)
+ *   by _bwd; out / d_out [n,4] = [rgb, sigma]. */
+int64_t fsn_nerf_train_workspace_floats(const fsn_mlp_desc* desc, int64_t n);
+int fsn_nerf_train_fwd(const fsn_mlp_desc* desc, const float* const* weights, const float* const* biases,
+                       const float* x, const float* dirs, const float* pos_mask, const float* dir_mask,
+                       int64_t n, float* workspace, float* out, fsn_stream_t stream);
+int fsn_nerf_train_bwd(const fsn_mlp_desc* desc, const float* const* weights, int64_t n, float* workspace,
+                       const float* out, const float* d_out, float* const* d_weights, float* const* d_biases,
+                       fsn_stream_t stream);
+/* backward of fsn_composite_packed_fwd with respect to sigmas and rgbs, given dL/dcolors [R,3] and
+ * (optional) dL/dopacity [R]; dL/ddepth is not propagated. */
+int fsn_composite_packed_bwd(const float* sigmas, const float* rgbs, const float* t_starts, const float* t_ends,
+                             const int64_t* ray_indices, int64_t N, int64_t R, const float* bkgd_host,
+                             const float* d_colors, const float* d_opacity, float* d_sigmas, float* d_rgbs,
+                             fsn_stream_t stream);
+
 /* f3: to8b(x) = (255 * clip(x, 0, 1)).astype(uint8)                    src/render/rendering.py:21 */
 int fsn_to8b(const float* x, int64_t n, uint8_t* out, fsn_stream_t stream);
 

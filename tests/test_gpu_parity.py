@@ -275,8 +275,9 @@ def test_nerf_forward_mask_skips_and_bf16(dev):
         got16 = m16(x.to(dev), d.to(dev))
     close(got16[:, :3], want[:, :3], rtol=0, atol=2e-2, what="bf16 rgb")
     m.train()
+    assert m(x.to(dev), d.to(dev)).requires_grad  # training forward (tests/test_train_step.py checks the gradients)
     with pytest.raises(NotImplementedError):
-        m(x.to(dev), d.to(dev))
+        m(x.to(dev))  # density-only forward has no backward
 
 
 # ------------------------------------------------------------------ a6 whole path
