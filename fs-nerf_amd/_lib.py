@@ -14,6 +14,7 @@ FSN_PREC_BF16X3 = 0
 FSN_PREC_BF16 = 1
 FSN_PREC_FP16X3 = 2
 FSN_PREC_FP16 = 3
+FSN_PREC_FP32 = 4  # training only: plain fp32 library GEMMs
 
 
 class MlpDesc(C.Structure):
@@ -56,9 +57,9 @@ SIGNATURES = {
     "fsn_render_rays_fused": (_i, [_PD, _i, _vp, _vp, C.POINTER(RenderArgs), _vp]),
     "fsn_occlusion_reg_fwd": (_i, [_vp, _vp, _vp, _i64, _i64, _f, _f, _i, _vp, _vp, _vp]),
     "fsn_to8b": (_i, [_vp, _i64, _vp, _vp]),
-    "fsn_nerf_train_workspace_floats": (_i64, [_PD, _i64]),
-    "fsn_nerf_train_fwd": (_i, [_PD, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
-    "fsn_nerf_train_bwd": (_i, [_PD, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fsn_nerf_train_workspace_floats": (_i64, [_PD, _i, _i64]),
+    "fsn_nerf_train_fwd": (_i, [_PD, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "fsn_nerf_train_bwd": (_i, [_PD, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fsn_composite_packed_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 

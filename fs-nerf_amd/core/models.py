@@ -39,9 +39,11 @@ class PositionalEncoder(nn.Module):
 
 
 class _NerfTrainFn(torch.autograd.Function):
-    """NeRF.forward with gradients (first version): fp32 activations are kept for the
-    backward, Linear layers run as fp32 library GEMMs (`fsn_nerf_train_fwd/_bwd`).  Gradients flow to the
-    parameters only (sample positions / directions need none on this path)."""
+    """NeRF.forward with gradients.  `fsn_nerf_train_fwd` runs the MFMA kernel of the inference
+    path with the fp32 activations saved; `fsn_nerf_train_bwd` the dgrad chain + wgrad GEMMs on the matrix cores
+    (csrc/train_fused.hip), in the model's precision mode; `train_precision="fp32"` selects the plain formulation
+    with fp32 library GEMMs instead.  Gradients flow to the parameters only (sample positions / directions need
+    none on this path)."""
 
     @staticmethod
     def forward(ctx, model, x, dirs, *params):
@@ -50,16 +52,16 @@ class _NerfTrainFn(torch.autograd.Function):
         desc = ops.make_desc(model.n_layers, model.d_hidden, model.skip, model.pos_encoder.freqs,
                              model.dir_encoder.freqs)
         dev = x.device
-        out, work = ops.nerf_train_fwd(desc, weights, biases, x, dirs, model._mask(model.pos_mask, dev),
+        prec = model.train_prec()
+        out, work = ops.nerf_train_fwd(desc, prec, weights, biases, x, dirs, model._mask(model.pos_mask, dev),
                                        model._mask(model.dir_mask, dev))
-        ctx.desc, ctx.work, ctx.out = desc, work, out
+        ctx.desc, ctx.prec, ctx.work, ctx.out = desc, prec, work, out
         ctx.weights = [w.detach() for w in weights]
-        ctx.lead = x.shape[:-1]
         return out.reshape(*x.shape[:-1], 4)
 
     @staticmethod
     def backward(ctx, d_out):
-        dW, db = ops.nerf_train_bwd(ctx.desc, ctx.weights, ctx.work, ctx.out, d_out.contiguous())
+        dW, db = ops.nerf_train_bwd(ctx.desc, ctx.prec, ctx.weights, ctx.work, ctx.out, d_out.contiguous())
         ctx.work = None
         db = [g.reshape(-1) for g in db]
         return (None, None, None, *dW, *db)
@@ -89,6 +91,7 @@ class NeRF(nn.Module):
         self.branch = nn.Linear(d_hidden + d_de, d_hidden // 2)
         self.rgb = nn.Linear(d_hidden // 2, 3)
         self.precision = precision
+        self.train_precision: Optional[str] = None  # None: same mode as `precision`; "fp32": plain library GEMMs
         self.pos_mask: Optional[Tensor] = None
         self.dir_mask: Optional[Tensor] = None
         self._packed = None
@@ -98,6 +101,10 @@ class NeRF(nn.Module):
     def set_freq_mask(self, pos_mask: Optional[Tensor], dir_mask: Optional[Tensor] = None) -> None:
         """Frequency mask multiplied onto the encoded features ([d_pos*(1+2n)], [d_dir*(1+2m)])."""
         self.pos_mask, self.dir_mask = pos_mask, dir_mask
+
+    def train_prec(self) -> int:
+        tp = self.train_precision or self.precision
+        return L.FSN_PREC_FP32 if tp == "fp32" else self.PRECISIONS[tp]
 
     def _tensors(self):
         mods = list(self.layers) + [self.sigma, self.connection, self.branch, self.rgb]

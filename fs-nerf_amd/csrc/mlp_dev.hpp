@@ -41,6 +41,7 @@ constexpr int kThreads = 64 * kWaves;
 constexpr int kGldsPerWave = kPhaseBytes / 1024 / kWaves;  // 1-KiB glds instructions per wave per phase
 constexpr int kRingBytes = kNSlot * kPhaseBytes;
 constexpr int kAuxCapFloats = 3456;  // LDS reserved per network for biases / heads (8x256 needs 3392)
+constexpr int kTileCols = 128;       // samples per workgroup tile = columns of a T-layout tile (train_fused.hip)
 
 struct Frag {  // one k-step (32 features x 16 samples) of activations as MFMA B operand
   s16x8 hi, lo;
@@ -220,9 +221,11 @@ __device__ __forceinline__ void sincos_f32(float a, float& s_out, float& c_out) 
 // Slot layout = enc_slot_feature() in mlp_layout.hpp; value = reference feature (models.py:37-39)
 // times the frequency mask (LDS, all ones when absent).  NKS k-steps (NKS*8 slots per lane; the
 // four lanes g = lane>>4 of a sample share the NKS*32 slots).
-template <int NKS, bool F16, bool X3>
+// `save` (training forward only, else null): this lane's column of the encoding's T-layout buffer at row 8g; slot
+// (k-step ks, element j) is stored at row 32 ks + 8 g + j, i.e. in B-operand order (train_fused.hip).
+template <int NKS, bool F16, bool X3, bool SAVE = false>
 __device__ __forceinline__ void encode(float x0, float x1, float x2, int n_freqs, const float* __restrict__ freqs,
-                                       const float* __restrict__ mask, int g, Frag (&out)[NKS]) {
+                                       const float* __restrict__ mask, int g, Frag (&out)[NKS], float* save = nullptr) {
   constexpr int SLOTS = 8 * NKS;
   float v[SLOTS];
   const int P = 3 * n_freqs;
@@ -244,12 +247,16 @@ __device__ __forceinline__ void encode(float x0, float x1, float x2, int n_freqs
     v[SLOTS - 1] = x1 * mask[1];
   }
   if (g == 3) v[SLOTS - 2] = x2 * mask[2];
+  if constexpr (SAVE) {
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q) save[((q >> 3) * 32 + (q & 7)) * kTileCols] = v[q];
+  }
 #pragma unroll
   for (int k = 0; k < NKS; ++k) split_store<F16, X3>(&v[8 * k], out[k]);
 }
 
 // ---------------------------------------------------------------- one GEMM layer
-enum : int { EPI_RELU_CVT = 0, EPI_LAST_FULL = 1, EPI_LAST_DENS = 4, EPI_CVT = 2, EPI_RGB = 3 };
+enum : int { EPI_RELU_CVT = 0, EPI_LAST_FULL = 1, EPI_LAST_DENS = 4, EPI_CVT = 2, EPI_RGB = 3, EPI_NONE = 5 };
 
 struct Heads {
   float sigma;  // partial dot (this lane group's features)
@@ -312,6 +319,15 @@ __device__ __forceinline__ float relu_f32(float v) {  // on the sign bit: one v_
   return __builtin_bit_cast(float, b < 0 ? 0 : b);
 }
 
+// Epilogue hooks.  A hook sees each finished output pair (8 fp32 values per lane, features
+// 32 tp + 16 (j>>2) + 4 g + (j&3) of this lane's sample) after the activation and before the 16-bit split.
+// Inference uses NoHook (no code); the training kernels (train_fused.hip) save / mask / store there.
+struct NoHook {
+  static constexpr bool kZeroInit = false;  // accumulators start from the bias
+  __device__ __forceinline__ void pre(int) {}
+  __device__ __forceinline__ void post(int, float (&)[8]) {}
+};
+
 // NP_OUT output pairs (32 features = two 16-row tiles); KS_ACT k-steps (of 32) from `act`, KS_ENC
 // from `enc`; units are consumed in (pair, k-step, half) order starting phase-aligned.  Epilogue
 // per finished pair (8 values per lane: features 32tp + 16(j>>2) + 4g + (j&3)):
@@ -319,10 +335,11 @@ __device__ __forceinline__ float relu_f32(float v) {  // on the sign bit: one v_
 //   EPI_LAST_*   : heads.sigma += w_sigma . relu(acc); _FULL also converts  (last hidden layer)
 //   EPI_CVT      : out[tp] = split(acc)                                        (connection)
 //   EPI_RGB      : heads.rgb[c] += w_rgb[c] . relu(acc)                        (branch)
-template <int PREC, int NP_OUT, int KS_ACT, int KS_ENC, int EPI, int NACT, int NENC, int NOUT>
+//   EPI_NONE     : nothing (the hook consumes the values; last GEMM of the backward chain)
+template <int PREC, int NP_OUT, int KS_ACT, int KS_ENC, int EPI, int NACT, int NENC, int NOUT, class HK>
 __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int aux_bias, const Frag (&act)[NACT],
                                            const Frag (&enc)[NENC], Frag (&out)[NOUT], Heads& heads, ARing& ring,
-                                           int g) {
+                                           int g, HK& hk) {
   constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
   static_assert(kLead == 2, "the A-operand prefetch distance (one k-step = two units) equals the phase lead");
   constexpr bool PREFETCH = !X3;
@@ -334,8 +351,12 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
   const float* bias = net.aux + aux_bias;
 #pragma unroll
   for (int tp = 0; tp < NP_OUT; ++tp) {
-    f32x4 acc0 = *reinterpret_cast<const f32x4*>(bias + 32 * tp + 4 * g);
-    f32x4 acc1 = *reinterpret_cast<const f32x4*>(bias + 32 * tp + 16 + 4 * g);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (!HK::kZeroInit) {
+      acc0 = *reinterpret_cast<const f32x4*>(bias + 32 * tp + 4 * g);
+      acc1 = *reinterpret_cast<const f32x4*>(bias + 32 * tp + 16 + 4 * g);
+    }
+    hk.pre(tp);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const Frag& b = ks < KS_ACT ? act[ks < KS_ACT ? ks : 0] : enc[ks >= KS_ACT ? ks - KS_ACT : 0];
@@ -379,10 +400,11 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
     float v[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { v[j] = acc0[j]; v[4 + j] = acc1[j]; }
-    if (EPI != EPI_CVT) {
+    if (EPI != EPI_CVT && EPI != EPI_NONE) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = relu_f32(v[j]);
     }
+    hk.post(tp, v);
     if (EPI == EPI_LAST_FULL || EPI == EPI_LAST_DENS) {
       const float* ws = net.aux + (net.n_layers + 2) * (NP_OUT * 32) + 32 * tp + 4 * g;
       const f32x4 w0 = *reinterpret_cast<const f32x4*>(ws), w1 = *reinterpret_cast<const f32x4*>(ws + 16);
@@ -424,6 +446,14 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
   }
 }
 
+template <int PREC, int NP_OUT, int KS_ACT, int KS_ENC, int EPI, int NACT, int NENC, int NOUT>
+__device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int aux_bias, const Frag (&act)[NACT],
+                                           const Frag (&enc)[NENC], Frag (&out)[NOUT], Heads& heads, ARing& ring,
+                                           int g) {
+  NoHook hk;
+  gemm_layer<PREC, NP_OUT, KS_ACT, KS_ENC, EPI>(st, net, aux_bias, act, enc, out, heads, ring, g, hk);
+}
+
 // A-operand pair primed for the very first GEMM of a kernel (after WStream::init opened phase 0)
 template <int PREC>
 __device__ __forceinline__ void prime_ring(const WStream& st, ARing& ring) {
@@ -438,9 +468,19 @@ __device__ __forceinline__ void prime_ring(const WStream& st, ARing& ring) {
 // `src` supplies this lane's sample on demand: src.pos(x,y,z) and src.dir(x,y,z) (the four lanes
 // l, l+16, l+32, l+48 hold the same sample).  The direction is read only in front of the branch
 // layer.  Outputs (valid in all lanes): sigma, and rgb when FULL.
-template <int NT, int PREC, bool FULL, class Src>
+// Saver of the inference kernels: nothing is kept.
+struct NoSave {
+  static constexpr bool kSave = false;
+  using Hook = NoHook;
+  __device__ __forceinline__ Hook hidden(int) const { return {}; }  // hidden layer l / connection (l = n_layers)
+  __device__ __forceinline__ Hook branch() const { return {}; }
+  __device__ __forceinline__ float* enc_pos(int) const { return nullptr; }
+  __device__ __forceinline__ float* enc_dir(int) const { return nullptr; }
+};
+
+template <int NT, int PREC, bool FULL, class Src, class SV>
 __device__ __forceinline__ void mlp_tile(WStream& st, const NetDev& net, const Src& src, ARing& ring, float& sigma,
-                                         float (&rgb)[3]) {
+                                         float (&rgb)[3], const SV& sv) {
   constexpr int NA = NT;  // k-steps of 32 across the hidden width
   constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
   const int g = (threadIdx.x >> 4) & 3;
@@ -454,15 +494,19 @@ __device__ __forceinline__ void mlp_tile(WStream& st, const NetDev& net, const S
   {
     float px, py, pz;
     src.pos(px, py, pz);
-    encode<kKsPos, F16, X3>(px, py, pz, net.n_freqs_pos, misc + 4, net.pos_mask, g, pe);
+    encode<kKsPos, F16, X3, SV::kSave>(px, py, pz, net.n_freqs_pos, misc + 4, net.pos_mask, g, pe, sv.enc_pos(g));
   }
-  gemm_layer<PREC, NT, 0, kKsPos, EPI_RELU_CVT>(st, net, 0, none, pe, A, heads, ring, g);
-#define FSN_HIDDEN(EPI, IN, OUT, LIDX)                                                    \
-  do {                                                                                    \
-    if ((net.skip_mask >> ((LIDX)-1)) & 1u)                                               \
-      gemm_layer<PREC, NT, NA, kKsPos, EPI>(st, net, (LIDX)*D, IN, pe, OUT, heads, ring, g);    \
-    else                                                                                  \
-      gemm_layer<PREC, NT, NA, 0, EPI>(st, net, (LIDX)*D, IN, none, OUT, heads, ring, g);       \
+  {
+    typename SV::Hook hk = sv.hidden(0);
+    gemm_layer<PREC, NT, 0, kKsPos, EPI_RELU_CVT>(st, net, 0, none, pe, A, heads, ring, g, hk);
+  }
+#define FSN_HIDDEN(EPI, IN, OUT, LIDX)                                                        \
+  do {                                                                                        \
+    typename SV::Hook hk = sv.hidden(LIDX);                                                   \
+    if ((net.skip_mask >> ((LIDX)-1)) & 1u)                                                   \
+      gemm_layer<PREC, NT, NA, kKsPos, EPI>(st, net, (LIDX)*D, IN, pe, OUT, heads, ring, g, hk);  \
+    else                                                                                      \
+      gemm_layer<PREC, NT, NA, 0, EPI>(st, net, (LIDX)*D, IN, none, OUT, heads, ring, g, hk);     \
   } while (0)
   for (int l = 1; l <= L - 2; l += 2) {
     FSN_HIDDEN(EPI_RELU_CVT, A, B, l);
@@ -484,12 +528,18 @@ __device__ __forceinline__ void mlp_tile(WStream& st, const NetDev& net, const S
   }
   if (FULL) {
     // connection (no activation, models.py:130), then branch on [feat, dir_enc] (models.py:131-133)
-    gemm_layer<PREC, NT, NA, 0, EPI_CVT>(st, net, L * D, B, none, A, heads, ring, g);
+    {
+      typename SV::Hook hk = sv.hidden(L);
+      gemm_layer<PREC, NT, NA, 0, EPI_CVT>(st, net, L * D, B, none, A, heads, ring, g, hk);
+    }
     Frag de[kKsDir];
     float dx, dy, dz;
     src.dir(dx, dy, dz);
-    encode<kKsDir, F16, X3>(dx, dy, dz, net.n_freqs_dir, misc + 20, net.dir_mask, g, de);
-    gemm_layer<PREC, NT / 2, NA, kKsDir, EPI_RGB>(st, net, (L + 1) * D, A, de, B, heads, ring, g);
+    encode<kKsDir, F16, X3, SV::kSave>(dx, dy, dz, net.n_freqs_dir, misc + 20, net.dir_mask, g, de, sv.enc_dir(g));
+    {
+      typename SV::Hook hk = sv.branch();
+      gemm_layer<PREC, NT / 2, NA, kKsDir, EPI_RGB>(st, net, (L + 1) * D, A, de, B, heads, ring, g, hk);
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       float z = heads.rgb[c];
@@ -499,6 +549,12 @@ __device__ __forceinline__ void mlp_tile(WStream& st, const NetDev& net, const S
       rgb[c] = 1.0f / (1.0f + expf(-z));  // sigmoid (models.py:135)
     }
   }
+}
+
+template <int NT, int PREC, bool FULL, class Src>
+__device__ __forceinline__ void mlp_tile(WStream& st, const NetDev& net, const Src& src, ARing& ring, float& sigma,
+                                         float (&rgb)[3]) {
+  mlp_tile<NT, PREC, FULL>(st, net, src, ring, sigma, rgb, NoSave{});
 }
 
 // Copy a blob's aux region and the two frequency masks into LDS (all threads of the workgroup;

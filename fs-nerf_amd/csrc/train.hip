@@ -15,6 +15,7 @@
 #include "common.hpp"
 #include "mlp_layout.hpp"
 #include "ray_dev.hpp"
+#include "train_internal.hpp"
 
 #include <dlfcn.h>
 
@@ -287,23 +288,27 @@ static int check_desc(const fsn_mlp_desc* d) {
 
 using namespace fsn;
 
-extern "C" int64_t fsn_nerf_train_workspace_floats(const fsn_mlp_desc* desc, int64_t n) {
+extern "C" int64_t fsn_nerf_train_workspace_floats(const fsn_mlp_desc* desc, int prec, int64_t n) {
   if (check_desc(desc) != FSN_OK) return FSN_E_INVALID;
   FSN_REQUIRE(n >= 0, FSN_E_INVALID, "fsn_nerf_train_workspace_floats: n < 0");
+  FSN_REQUIRE(prec >= 0 && prec <= FSN_PREC_FP32, FSN_E_INVALID, "fsn_nerf_train_workspace_floats: unknown precision");
+  if (prec != FSN_PREC_FP32) return fused_train_workspace_floats(*desc, prec, n);
   TrainLayout T;
   make_layout(*desc, n, T);
   return T.total;
 }
 
-extern "C" int fsn_nerf_train_fwd(const fsn_mlp_desc* desc, const float* const* W, const float* const* b, const float* x,
-                                  const float* dirs, const float* pos_mask, const float* dir_mask, int64_t n,
-                                  float* ws, float* out, fsn_stream_t stream) {
+extern "C" int fsn_nerf_train_fwd(const fsn_mlp_desc* desc, int prec, const float* const* W, const float* const* b,
+                                  const float* x, const float* dirs, const float* pos_mask, const float* dir_mask,
+                                  int64_t n, float* ws, float* out, fsn_stream_t stream) {
   int rc = check_desc(desc);
   if (rc != FSN_OK) return rc;
+  FSN_REQUIRE(prec >= 0 && prec <= FSN_PREC_FP32, FSN_E_INVALID, "fsn_nerf_train_fwd: unknown precision");
   if (n == 0) return FSN_OK;
   FSN_REQUIRE(W && b && x && dirs && ws && out, FSN_E_INVALID, "fsn_nerf_train_fwd: null pointer");
   FSN_REQUIRE(n < (1ll << 31), FSN_E_UNSUPPORTED, "fsn_nerf_train_fwd: n too large for one call");
   hipStream_t s = as_stream(stream);
+  if (prec != FSN_PREC_FP32) return fused_train_fwd(desc, prec, W, b, x, dirs, pos_mask, dir_mask, n, ws, out, s);
   RocBlas* rb;
   rc = rb_get(s, &rb);
   if (rc != FSN_OK) return rc;
@@ -357,13 +362,18 @@ extern "C" int fsn_nerf_train_fwd(const fsn_mlp_desc* desc, const float* const* 
   return FSN_OK;
 }
 
-extern "C" int fsn_nerf_train_bwd(const fsn_mlp_desc* desc, const float* const* W, int64_t n, float* ws, const float* out,
-                                  const float* d_out, float* const* dW, float* const* db, fsn_stream_t stream) {
+extern "C" int fsn_nerf_train_bwd(const fsn_mlp_desc* desc, int prec, const float* const* W, int64_t n, float* ws,
+                                  const float* out, const float* d_out, const float* grad_scale, float* const* dW,
+                                  float* const* db, fsn_stream_t stream) {
   int rc = check_desc(desc);
   if (rc != FSN_OK) return rc;
+  FSN_REQUIRE(prec >= 0 && prec <= FSN_PREC_FP32, FSN_E_INVALID, "fsn_nerf_train_bwd: unknown precision");
   FSN_REQUIRE(W && dW && db, FSN_E_INVALID, "fsn_nerf_train_bwd: null pointer");
   FSN_REQUIRE(n > 0 && ws && out && d_out, FSN_E_INVALID, "fsn_nerf_train_bwd: needs the forward's workspace (n > 0)");
+  FSN_REQUIRE(n < (1ll << 31), FSN_E_UNSUPPORTED, "fsn_nerf_train_bwd: n too large for one call");
   hipStream_t s = as_stream(stream);
+  if (prec != FSN_PREC_FP32) return fused_train_bwd(desc, prec, W, n, ws, out, d_out, grad_scale, dW, db, s);
+  FSN_REQUIRE(!grad_scale, FSN_E_INVALID, "fsn_nerf_train_bwd: grad_scale applies to the 16-bit MFMA modes only");
   RocBlas* rb;
   rc = rb_get(s, &rb);
   if (rc != FSN_OK) return rc;

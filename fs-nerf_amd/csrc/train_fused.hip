@@ -1,0 +1,842 @@
+// train_fused.hip — the training step of NeRF.forward on the matrix cores.
+//
+//   k_train_fwd   : the inference MLP kernel (mlp_dev.hpp) with a saver hooked into every epilogue: the fp32
+//                   encodings, post-activation hidden layers, connection output and branch output go to HBM.
+//   k_train_bwd   : the dgrad chain in the same register-resident form.  d(out) -> rgb/sigma heads (VALU) ->
+//                   branch^T -> connection^T -> layers L-1..1 transposed, each an MFMA GEMM whose A operands are
+//                   the TRANSPOSED weights streamed through LDS exactly like the forward's; the ReLU mask comes
+//                   from the saved activations; every pre-activation gradient dPre_l is stored for the wgrad.
+//   k_wgrad       : dW_l = dPre_l . H_{l-1}^T, a GEMM whose contraction runs over ALL samples (K = millions,
+//                   output 256x256): split-K over sample tiles, v_mfma_f32_32x32x16, one 256x256 (or smaller)
+//                   fp32 accumulator block per workgroup in registers, partial blocks reduced in fixed order
+//                   (deterministic) by k_wgrad_reduce, which also undoes the slot permutation of the encodings.
+//   k_heads_wgrad : sigma / rgb head weights (1 and 3 output rows): HBM-bound row dot products.
+//
+// "T-layout" of every saved matrix: tiles of 128 samples (one workgroup tile), [tile][row = feature][128 samples]
+// fp32.  It is what the accumulator layout of the transposed MLP stores with 64-byte row segments, and it makes
+// BOTH wgrad operands contiguous along the contraction (sample) axis, so they load straight into MFMA operands.
+//
+// Precision: as the forward, split 16-bit x 3 passes with fp32 accumulation.  In the fp16 modes d(out) is
+// multiplied by a power-of-two `grad_scale` on entry (and the result divided by it in the reduce) so that the
+// gradients sit in fp16's range; bf16 modes need none.
+//
+// reference: src/core/models.py:111-143 (forward), src/run-nerf.py:243-285 (loss.backward()).
+#include "mlp_dev.hpp"
+#include "mlp_layout.hpp"
+#include "train_internal.hpp"
+
+namespace fsn {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+constexpr int kTC = kTileCols;
+
+// ------------------------------------------------------------------ workspace
+struct FusedLayout {
+  int L, D, NT, d_pe, d_de, prec;
+  int64_t T;  // sample tiles
+  int64_t blob_f, blob_b;
+  int64_t pe, de, h, h_stride, bo, dhead, dbo, dp, part, hpart, total;  // float offsets
+  int nsplit, nsplit_heads, n_bwd_units, nph_bwd;
+  int64_t blob_f_bytes;
+};
+
+static int n_big_jobs(const fsn_mlp_desc& d) { return d.n_layers + 1; }  // layers 1..L-1, connection, branch
+
+static int64_t part_floats(const fsn_mlp_desc& d, int nsplit) {
+  const int64_t D = d.d_hidden, L = d.n_layers;
+  int64_t per = 0;
+  per += (L - 1 + 1) * (D * D + D);                                   // hidden 1..L-1, connection
+  int n_pe = 1;
+  for (int l = 1; l < L; ++l) n_pe += (d.skip_mask >> (l - 1)) & 1u;
+  per += n_pe * (D * 64 + D);                                          // encoding columns of layer 0 / wide layers
+  per += (D / 2) * D + D / 2;                                          // branch (features)
+  per += (D / 2) * 32 + D / 2;                                         // branch (direction encoding)
+  return per * nsplit;
+}
+
+static int make_fused_layout(const fsn_mlp_desc& d, int prec, int64_t n, FusedLayout& F, const char** why) {
+  NetGeom G;
+  const int rc = build_geom(d, prec, G, why);
+  if (rc != FSN_OK) return rc;
+  F.L = d.n_layers; F.D = d.d_hidden; F.NT = F.D / 32; F.prec = prec;
+  F.d_pe = 3 * (1 + 2 * d.n_freqs_pos); F.d_de = 3 * (1 + 2 * d.n_freqs_dir);
+  F.T = (n + kTC - 1) / kTC;
+  int cus = fsn_device_cus();
+  if (cus <= 0) cus = 256;  // sizing query without a device
+  int64_t ns = cus / n_big_jobs(d);
+  if (ns < 1) ns = 1;
+  if (ns > F.T) ns = F.T;
+  if (ns < 1) ns = 1;
+  F.nsplit = (int)ns;
+  F.nsplit_heads = (int)(F.T < cus ? (F.T > 0 ? F.T : 1) : cus);
+  const int NT = F.NT;
+  F.n_bwd_units = NT * NT + 2 * NT * NT + (F.L - 1) * 2 * NT * NT;
+  const int upp = units_per_phase(prec);
+  F.nph_bwd = (F.n_bwd_units + upp - 1) / upp;
+  F.blob_f_bytes = G.total_bytes;
+  auto al = [](int64_t floats) { return (floats + 1023) / 1024 * 1024; };  // 4-KiB granules
+  int64_t o = 0;
+  F.blob_f = o; o += al(G.total_bytes / 4 + 1);
+  F.blob_b = o; o += al((int64_t)F.nph_bwd * kPhaseBytes / 4);
+  const int64_t T = F.T, D = F.D;
+  F.pe = o; o += T * 64 * kTC;
+  F.de = o; o += T * 32 * kTC;
+  F.h_stride = T * D * kTC;
+  F.h = o; o += (F.L + 1) * F.h_stride;  // H_0..H_{L-1}, connection output
+  F.bo = o; o += T * (D / 2) * kTC;
+  F.dhead = o; o += T * 4 * kTC;
+  F.dbo = o; o += T * (D / 2) * kTC;
+  F.dp = o; o += (F.L + 1) * F.h_stride;  // dPre_0..dPre_{L-1}, d(connection output)
+  F.part = o; o += al(part_floats(d, F.nsplit));
+  F.hpart = o; o += al((int64_t)F.nsplit_heads * (D + 3 * (D / 2) + 4));
+  F.total = o;
+  return FSN_OK;
+}
+
+// ------------------------------------------------------------------ forward with saved activations
+struct FwdSaver {
+  static constexpr bool kSave = true;
+  struct Hook {
+    static constexpr bool kZeroInit = false;
+    float* p;
+    __device__ __forceinline__ void pre(int) {}
+    __device__ __forceinline__ void post(int tp, float (&v)[8]) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) p[(32 * tp + 16 * (j >> 2) + (j & 3)) * kTC] = v[j];
+    }
+  };
+  float* h0;  // this lane's column, row 4g, of H_0's tile
+  int64_t hstride;
+  float *bo, *pe, *de;
+  __device__ __forceinline__ Hook hidden(int l) const { return Hook{h0 + l * hstride}; }
+  __device__ __forceinline__ Hook branch() const { return Hook{bo}; }
+  __device__ __forceinline__ float* enc_pos(int) const { return pe; }
+  __device__ __forceinline__ float* enc_dir(int) const { return de; }
+};
+
+struct TrainFwdArgs {
+  NetParams net;
+  const float *x, *dirs, *pos_mask, *dir_mask;
+  int64_t n;
+  float* out;
+  float* ws;
+  int64_t off_h, h_stride, off_bo, off_pe, off_de;
+  int32_t D;
+};
+
+struct TileSrcT {
+  const float* p;
+  __device__ __forceinline__ void pos(float& x, float& y, float& z) const { x = p[0]; y = p[1]; z = p[2]; }
+  __device__ __forceinline__ void dir(float& x, float& y, float& z) const { x = p[3]; y = p[4]; z = p[5]; }
+};
+
+template <int NT, int PREC>
+__global__ __launch_bounds__(kThreads) void k_train_fwd(TrainFwdArgs a) {
+  __shared__ __attribute__((aligned(1024))) char smem[kRingBytes + (kAuxCapFloats + 96) * 4 + 128 * 6 * 4];
+  float* aux_lds = reinterpret_cast<float*>(smem + kRingBytes);
+  float* in_lds = aux_lds + kAuxCapFloats + 96;
+  NetDev net;
+  load_net(a.net, a.pos_mask, a.dir_mask, aux_lds, net);
+  __syncthreads();
+  constexpr int D = 32 * NT;
+  const int64_t ntiles = (a.n + kTC - 1) / kTC;
+  WStream st;
+  st.init(smem, nullptr, 0, 0, a.net.blob + a.net.stream_off, (uint32_t)a.net.nph_full, 1);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4;
+  const int col = wave * 16 + (lane & 15);
+  ARing ring;
+  prime_ring<PREC>(st, ring);
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t s = tile * kTC + col;
+    const int64_t sc = s < a.n ? s : a.n - 1;
+    if (lane < 16) {
+      float* q = in_lds + col * 6;
+      q[0] = a.x[3 * sc]; q[1] = a.x[3 * sc + 1]; q[2] = a.x[3 * sc + 2];
+      q[3] = a.dirs[3 * sc]; q[4] = a.dirs[3 * sc + 1]; q[5] = a.dirs[3 * sc + 2];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const TileSrcT src{in_lds + col * 6};
+    FwdSaver sv;
+    sv.h0 = a.ws + a.off_h + (tile * D + 4 * g) * kTC + col;
+    sv.hstride = a.h_stride;
+    sv.bo = a.ws + a.off_bo + (tile * (D / 2) + 4 * g) * kTC + col;
+    sv.pe = a.ws + a.off_pe + (tile * 64 + 8 * g) * kTC + col;
+    sv.de = a.ws + a.off_de + (tile * 32 + 8 * g) * kTC + col;
+    float sigma, rgb[3] = {0.f, 0.f, 0.f};
+    mlp_tile<NT, PREC, true>(st, net, src, ring, sigma, rgb, sv);
+    if (lane < 16 && s < a.n) {
+      f32x4 o = {rgb[0], rgb[1], rgb[2], sigma};
+      *reinterpret_cast<f32x4*>(a.out + 4 * s) = o;
+    }
+  }
+  st.drain();
+}
+
+// ------------------------------------------------------------------ backward blob (transposed weights)
+struct BwdPackArgs {
+  const float* W[kMaxLayers + 2];
+  int32_t ld[kMaxLayers + 2], ks[kMaxLayers + 2], unit0[kMaxLayers + 2];
+  int32_t n_gemm, units_total, prec, NT;
+};
+
+// A operand element (row i = input feature of the layer, k = o = output feature) = W[o][i]; the k order inside a
+// k-step is the accumulator-as-operand order of mlp_layout.hpp (o = 32 ks + 16 (j>>2) + 4 g + (j&3)).
+__global__ void k_pack_bwd(BwdPackArgs a, char* __restrict__ stream, int64_t n_pieces) {
+  const int64_t piece = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (piece >= n_pieces) return;
+  const int ub = unit_bytes(a.prec), ppu = ub / 16;
+  const int unit = (int)(piece / ppu);
+  const int rem = (int)(piece - (int64_t)unit * ppu);
+  const int part = rem >> 6, lane = rem & 63;
+  uint16_t o8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (unit < a.units_total) {
+    int gi = 0;
+    while (gi + 1 < a.n_gemm && a.unit0[gi + 1] <= unit) ++gi;
+    const int lu = unit - a.unit0[gi];
+    const int sub = lu & 1, kst = a.ks[gi];
+    const int t = (lu >> 1) / kst, ks = (lu >> 1) - t * kst;
+    const int r = lane & 15, grp = lane >> 4;
+    const int row = 32 * t + 16 * sub + r;
+    const float* W = a.W[gi];
+    const int ld = a.ld[gi];
+    const bool f16 = prec_is_f16(a.prec);
+    for (int j = 0; j < 8; ++j) {
+      const int oc = 32 * ks + 16 * (j >> 2) + 4 * grp + (j & 3);
+      const float w = W[(int64_t)oc * ld + row];
+      const uint16_t hi = half_rne(w, f16);
+      o8[j] = part == 0 ? hi : half_rne(w - half_to_f32(hi, f16), f16);
+    }
+  }
+  uint4 v;
+  v.x = o8[0] | ((uint32_t)o8[1] << 16);
+  v.y = o8[2] | ((uint32_t)o8[3] << 16);
+  v.z = o8[4] | ((uint32_t)o8[5] << 16);
+  v.w = o8[6] | ((uint32_t)o8[7] << 16);
+  *reinterpret_cast<uint4*>(stream + piece * 16) = v;
+}
+
+// ------------------------------------------------------------------ backward chain (dgrad)
+struct BwdStoreHook {
+  static constexpr bool kZeroInit = true;
+  float* d;
+  __device__ __forceinline__ void pre(int) {}
+  __device__ __forceinline__ void post(int tp, float (&v)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[(32 * tp + 16 * (j >> 2) + (j & 3)) * kTC] = v[j];
+  }
+};
+
+template <bool ADD_SIGMA>
+struct BwdMaskHook {
+  static constexpr bool kZeroInit = true;
+  const float* h;     // saved activation of the layer whose pre-activation gradient this is
+  float* d;           // dPre destination
+  float dsig;         // d sigma of this lane's sample
+  const float* wsig;  // LDS: w_sigma + 4g
+  float hv[8];
+  __device__ __forceinline__ void pre(int tp) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) hv[j] = h[(32 * tp + 16 * (j >> 2) + (j & 3)) * kTC];
+  }
+  __device__ __forceinline__ void post(int tp, float (&v)[8]) {
+    if (ADD_SIGMA) {  // sigma = w_sigma . h_{L-1} + b (models.py:127)
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(wsig + 32 * tp);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(wsig + 32 * tp + 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = v[j] + dsig * w0[j];
+        v[4 + j] = v[4 + j] + dsig * w1[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      v[j] = hv[j] > 0.f ? v[j] : 0.f;
+      d[(32 * tp + 16 * (j >> 2) + (j & 3)) * kTC] = v[j];
+    }
+  }
+};
+
+struct TrainBwdArgs {
+  NetParams net;       // forward blob: aux region (w_sigma, w_rgb)
+  const char* bstream;  // transposed-weight stream
+  int32_t nph_bwd;
+  int64_t n;
+  const float *out, *d_out, *scale;
+  float* ws;
+  int64_t off_h, h_stride, off_bo, off_dhead, off_dbo, off_dp;
+};
+
+template <int NT, int PREC>
+__global__ __launch_bounds__(kThreads) void k_train_bwd(TrainBwdArgs a) {
+  constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
+  __shared__ __attribute__((aligned(1024))) char smem[kRingBytes + (kAuxCapFloats + 96) * 4];
+  float* aux_lds = reinterpret_cast<float*>(smem + kRingBytes);
+  NetDev net;
+  load_net(a.net, nullptr, nullptr, aux_lds, net);
+  __syncthreads();
+  constexpr int D = 32 * NT;
+  const int L = net.n_layers;
+  const int64_t ntiles = (a.n + kTC - 1) / kTC;
+  WStream st;
+  st.init(smem, nullptr, 0, 0, a.bstream, (uint32_t)a.nph_bwd, 1);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4;
+  const int col = wave * 16 + (lane & 15);
+  const float scale = a.scale ? a.scale[0] : 1.0f;
+  ARing ring;
+  prime_ring<PREC>(st, ring);
+  Heads heads{0.f, {0.f, 0.f, 0.f}};
+  Frag none[1];
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t s = tile * kTC + col;
+    const bool valid = s < a.n;
+    f32x4 o4 = {0.f, 0.f, 0.f, 0.f}, d4 = {0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+      o4 = *reinterpret_cast<const f32x4*>(a.out + 4 * s);
+      d4 = *reinterpret_cast<const f32x4*>(a.d_out + 4 * s);
+    }
+    // rgb = sigmoid(z): dz = d rgb * rgb (1 - rgb) (models.py:135); sigma head is linear (models.py:127)
+    float dz[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dz[c] = (d4[c] * scale) * o4[c] * (1.0f - o4[c]);
+    const float dsig = d4[3] * scale;
+    if (lane < 16) {
+      float* dh = a.ws + a.off_dhead + tile * 4 * kTC + col;
+      dh[0] = dz[0]; dh[kTC] = dz[1]; dh[2 * kTC] = dz[2]; dh[3 * kTC] = dsig;
+    }
+    const int64_t lane_off = (tile * D + 4 * g) * kTC + col;         // row 4g of a D-row tile
+    const int64_t lane_off_h = (tile * (D / 2) + 4 * g) * kTC + col;  // ... of a D/2-row tile
+    Frag A[NT], B[NT];
+    {  // branch output: d Bo = W_rgb^T dz, masked by Bo > 0 (models.py:133-134), VALU
+      const float* bo = a.ws + a.off_bo + lane_off_h;
+      float* dbo = a.ws + a.off_dbo + lane_off_h;
+      const float* wr = net.aux + (L + 3) * D + 4 * g;
+#pragma unroll
+      for (int ks = 0; ks < NT / 2; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr + 32 * ks + 16 * hh);
+          const f32x4 w1 = *reinterpret_cast<const f32x4*>(wr + (D / 2) + 32 * ks + 16 * hh);
+          const f32x4 w2 = *reinterpret_cast<const f32x4*>(wr + 2 * (D / 2) + 32 * ks + 16 * hh);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int off = (32 * ks + 16 * hh + j) * kTC;
+            const float val = (dz[0] * w0[j] + dz[1] * w1[j]) + dz[2] * w2[j];
+            const float r = bo[off] > 0.f ? val : 0.f;
+            dbo[off] = r;
+            v[4 * hh + j] = r;
+          }
+        }
+        split_store<F16, X3>(v, B[ks]);
+      }
+    }
+    {  // d feat = W_branch[:, :D]^T dBo  -> "dPre" of the connection (no activation, models.py:130)
+      BwdStoreHook hk{a.ws + a.off_dp + L * a.h_stride + lane_off};
+      gemm_layer<PREC, NT, NT / 2, 0, EPI_CVT>(st, net, 0, B, none, A, heads, ring, g, hk);
+    }
+    {  // d h_{L-1} = W_conn^T d feat + d sigma w_sigma, masked by h_{L-1} > 0
+      BwdMaskHook<true> hk;
+      hk.h = a.ws + a.off_h + (L - 1) * a.h_stride + lane_off;
+      hk.d = a.ws + a.off_dp + (L - 1) * a.h_stride + lane_off;
+      hk.dsig = dsig;
+      hk.wsig = net.aux + (L + 2) * D + 4 * g;
+      gemm_layer<PREC, NT, NT, 0, EPI_CVT>(st, net, 0, A, none, B, heads, ring, g, hk);
+    }
+    // B = dPre_{l}; layers l = L-1 .. 1: dPre_{l-1} = (W_l[:, :D]^T dPre_l) * (h_{l-1} > 0)
+    for (int l = L - 1; l >= 1; l -= 2) {
+      {
+        BwdMaskHook<false> hk;
+        hk.h = a.ws + a.off_h + (l - 1) * a.h_stride + lane_off;
+        hk.d = a.ws + a.off_dp + (l - 1) * a.h_stride + lane_off;
+        gemm_layer<PREC, NT, NT, 0, EPI_CVT>(st, net, 0, B, none, A, heads, ring, g, hk);
+      }
+      if (l - 1 >= 1) {
+        BwdMaskHook<false> hk;
+        hk.h = a.ws + a.off_h + (l - 2) * a.h_stride + lane_off;
+        hk.d = a.ws + a.off_dp + (l - 2) * a.h_stride + lane_off;
+        gemm_layer<PREC, NT, NT, 0, EPI_CVT>(st, net, 0, A, none, B, heads, ring, g, hk);
+      }
+    }
+  }
+  st.drain();
+}
+
+// ------------------------------------------------------------------ wgrad
+struct WgJob {
+  const float* A;  // dPre, T-layout with a_rows rows
+  const float* B;  // layer input, T-layout with b_rows rows
+  float* part;     // [nsplit][a_rows][b_rows]
+  float* bpart;    // [nsplit][a_rows] row sums of A (bias gradient)
+  int32_t b_rows;
+};
+constexpr int kMaxJobs = kMaxLayers + 2;
+struct WgArgs {
+  WgJob job[kMaxJobs];
+  int64_t T;
+  int32_t nsplit;
+};
+
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma32(const s16x8& a, const s16x8& b, const f32x16& c) {
+  if (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// Workgroup = 8 waves as MG row groups (64 rows of A each: two 32-row MFMA tiles) x CG = 8/MG column groups
+// (BT 32-row tiles of B each).  Per 32-sample chunk: the B rows are converted to 16-bit high/low parts and
+// staged in LDS in MFMA-operand order (double buffered, register prefetch of the next chunk); each wave loads
+// its own A rows straight from HBM/L2 (32 contiguous bytes per lane and k-step), converts them in registers
+// and accumulates their row sums for the bias gradient.
+template <int MG, int BT, int PREC>
+__global__ __launch_bounds__(kThreads) void k_wgrad(WgArgs a) {
+  constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
+  constexpr int CG = 8 / MG;
+  constexpr int A_ROWS = 64 * MG;
+  constexpr int B_ROWS_MAX = CG * BT * 32;
+  constexpr int NB = (B_ROWS_MAX * 4 + kThreads - 1) / kThreads;  // staged items per thread
+  __shared__ __attribute__((aligned(16))) char lds[2][2][B_ROWS_MAX * 64];  // [buffer][hi/lo][(tile,kstep,lane) x 16 B]
+  const WgJob jb = a.job[blockIdx.y];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int rg = wave % MG, cg = wave / MG;
+  const int m = lane & 31, kg = lane >> 5;
+  const int b_rows = jb.b_rows;
+  const bool active = cg * BT * 32 < b_rows;
+  const int64_t t0 = (int64_t)blockIdx.x * a.T / a.nsplit, t1 = (int64_t)(blockIdx.x + 1) * a.T / a.nsplit;
+  const int64_t nchunk = (t1 - t0) * 4;
+
+  f32x16 acc[2][BT];
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ti][bt][r] = 0.f;
+  float bsum[2] = {0.f, 0.f};
+
+  // staging item q = it*512 + tid: row R = 16 (q>>6) + (q&15), sample group sg = (q>>4)&3
+  const int sg = (tid >> 4) & 3;
+  f32x4 braw[NB][2];
+  f32x4 araw[2][2][2];  // [tile][k-step][half]
+  auto load_chunk = [&](int64_t ci) {
+    const int64_t t = t0 + (ci >> 2);
+    const int c = (int)(ci & 3);
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+      const int R = 16 * ((it * kThreads + tid) >> 6) + (tid & 15);
+      if (R < b_rows) {
+        const float* p = jb.B + (t * b_rows + R) * kTC + 32 * c + 8 * sg;
+        braw[it][0] = *reinterpret_cast<const f32x4*>(p);
+        braw[it][1] = *reinterpret_cast<const f32x4*>(p + 4);
+      }
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const float* p = jb.A + (t * A_ROWS + 64 * rg + 32 * ti + m) * kTC + 32 * c + 16 * ks + 8 * kg;
+        araw[ti][ks][0] = *reinterpret_cast<const f32x4*>(p);
+        araw[ti][ks][1] = *reinterpret_cast<const f32x4*>(p + 4);
+      }
+  };
+  auto stage_b = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+      const int R = 16 * ((it * kThreads + tid) >> 6) + (tid & 15);
+      if (R < b_rows) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = braw[it][0][j]; v[4 + j] = braw[it][1][j]; }
+        Frag f;
+        split_store<F16, X3>(v, f);
+        const int addr = ((((R >> 5) * 2 + (sg >> 1)) * 64) + (sg & 1) * 32 + (R & 31)) * 16;
+        *reinterpret_cast<s16x8*>(&lds[buf][0][addr]) = f.hi;
+        if (X3) *reinterpret_cast<s16x8*>(&lds[buf][1][addr]) = f.lo;
+      }
+    }
+  };
+
+  if (nchunk > 0) {
+    load_chunk(0);
+    stage_b(0);
+  }
+  __syncthreads();
+  for (int64_t ci = 0; ci < nchunk; ++ci) {
+    const int buf = (int)(ci & 1);
+    // this chunk's A operands: fp32 -> 16-bit parts (and the bias row sums)
+    Frag af[2][2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = araw[ti][ks][0][j]; v[4 + j] = araw[ti][ks][1][j]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum[ti] += v[j];
+        split_store<F16, X3>(v, af[ti][ks]);
+      }
+    if (ci + 1 < nchunk) load_chunk(ci + 1);  // next chunk's global loads fly under the MFMAs
+    if (active) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int bt = 0; bt < BT; ++bt) {
+          const int addr = (((cg * BT + bt) * 2 + ks) * 64 + lane) * 16;
+          const s16x8 bh = *reinterpret_cast<const s16x8*>(&lds[buf][0][addr]);
+          s16x8 bl = bh;
+          if (X3) bl = *reinterpret_cast<const s16x8*>(&lds[buf][1][addr]);
+#pragma unroll
+          for (int ti = 0; ti < 2; ++ti) {
+            acc[ti][bt] = mfma32<F16>(af[ti][ks].hi, bh, acc[ti][bt]);
+            if (X3) {
+              acc[ti][bt] = mfma32<F16>(af[ti][ks].lo, bh, acc[ti][bt]);
+              acc[ti][bt] = mfma32<F16>(af[ti][ks].hi, bl, acc[ti][bt]);
+            }
+          }
+        }
+    }
+    if (ci + 1 < nchunk) stage_b(buf ^ 1);
+    __syncthreads();
+  }
+  // partial block: C layout of the 32x32 tile: column = lane&31, row = (r&3) + 8 (r>>2) + 4 (lane>>5)
+  if (active) {
+    float* part = jb.part + (int64_t)blockIdx.x * A_ROWS * b_rows;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int bt = 0; bt < BT; ++bt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = 64 * rg + 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * kg;
+          const int cc = (cg * BT + bt) * 32 + m;
+          part[(int64_t)row * b_rows + cc] = acc[ti][bt][r];
+        }
+  }
+  if (jb.bpart && cg == 0) {
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+      const float v = bsum[ti] + __shfl_xor(bsum[ti], 32, 64);
+      if (kg == 0) jb.bpart[(int64_t)blockIdx.x * A_ROWS + 64 * rg + 32 * ti + m] = v;
+    }
+  }
+}
+
+struct RdJob {
+  const float* part;
+  const float* bpart;
+  float* dW;
+  float* db;
+  int32_t a_rows, b_rows, ld, col0, mode, n_freqs;  // mode 0: column = col0 + c; 1/2: position/direction slots
+};
+struct RdArgs {
+  RdJob job[2 * kMaxLayers + 4];
+  int32_t nsplit;
+  const float* scale;
+};
+
+__global__ void k_wgrad_reduce(RdArgs a) {
+  const RdJob jb = a.job[blockIdx.y];
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const float inv = a.scale ? 1.0f / a.scale[0] : 1.0f;
+  const int tot = jb.a_rows * jb.b_rows;
+  if (e < tot) {
+    const int row = e / jb.b_rows, c = e - row * jb.b_rows;
+    int colo;
+    if (jb.mode == 0) {
+      colo = jb.col0 + c;
+    } else {
+      const int slots = jb.mode == 1 ? 8 * kKsPos : 8 * kKsDir;
+      const int ks = c >> 5, gq = (c >> 3) & 3, j = c & 7;
+      const int f = enc_slot_feature(8 * ks + j, gq, jb.n_freqs, slots);
+      colo = f < 0 ? -1 : jb.col0 + f;
+    }
+    if (colo >= 0) {
+      float sum = 0.f;
+      for (int p = 0; p < a.nsplit; ++p) sum += jb.part[(int64_t)p * tot + e];
+      jb.dW[(int64_t)row * jb.ld + colo] = sum * inv;
+    }
+  }
+  if (jb.bpart && e < jb.a_rows) {
+    float sum = 0.f;
+    for (int p = 0; p < a.nsplit; ++p) sum += jb.bpart[(int64_t)p * jb.a_rows + e];
+    jb.db[e] = sum * inv;
+  }
+}
+
+// ------------------------------------------------------------------ head weights
+// dW_sigma[f] = sum_s dsigma_s h_{L-1}[f,s];  dW_rgb[c,f] = sum_s dz_c,s Bo[f,s];  biases = sums of dsigma / dz.
+// Wave w owns 4 NT rows of h_{L-1} and 2 NT rows of Bo; lanes run along the samples (512-byte coalesced rows).
+struct HeadsArgs {
+  const float *H, *Bo, *dhead;
+  float* hpart;  // [nsplit][D + 3 D/2 + 4]
+  int64_t T;
+  int32_t nsplit;
+};
+
+template <int NT>
+__global__ __launch_bounds__(kThreads) void k_heads_wgrad(HeadsArgs a) {
+  constexpr int D = 32 * NT, RS = 4 * NT, RR = 2 * NT;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t t0 = (int64_t)blockIdx.x * a.T / a.nsplit, t1 = (int64_t)(blockIdx.x + 1) * a.T / a.nsplit;
+  float accS[RS], accR[3][RR], accB[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < RS; ++r) accS[r] = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < RR; ++r) accR[c][r] = 0.f;
+  for (int64_t t = t0; t < t1; ++t) {
+    f32x2 dh[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dh[c] = *reinterpret_cast<const f32x2*>(a.dhead + (t * 4 + c) * kTC + 2 * lane);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) accB[c] += dh[c][0] + dh[c][1];
+    const float* hp = a.H + (t * D + RS * wave) * kTC + 2 * lane;
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+      const f32x2 h = *reinterpret_cast<const f32x2*>(hp + r * kTC);
+      accS[r] += dh[3][0] * h[0] + dh[3][1] * h[1];
+    }
+    const float* bp = a.Bo + (t * (D / 2) + RR * wave) * kTC + 2 * lane;
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+      const f32x2 b = *reinterpret_cast<const f32x2*>(bp + r * kTC);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) accR[c][r] += dh[c][0] * b[0] + dh[c][1] * b[1];
+    }
+  }
+  float* out = a.hpart + (int64_t)blockIdx.x * (D + 3 * (D / 2) + 4);
+  auto wsum = [](float v) {
+#pragma unroll
+    for (int mm = 32; mm >= 1; mm >>= 1) v += __shfl_xor(v, mm, 64);
+    return v;
+  };
+#pragma unroll
+  for (int r = 0; r < RS; ++r) {
+    const float v = wsum(accS[r]);
+    if (lane == 0) out[RS * wave + r] = v;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+      const float v = wsum(accR[c][r]);
+      if (lane == 0) out[D + c * (D / 2) + RR * wave + r] = v;
+    }
+  if (wave == 0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float v = wsum(accB[c]);
+      if (lane == 0) out[D + 3 * (D / 2) + c] = v;
+    }
+  }
+}
+
+struct HeadsRdArgs {
+  const float* hpart;
+  int32_t nsplit, D;
+  const float* scale;
+  float *dWs, *dbs, *dWr, *dbr;
+};
+__global__ void k_heads_reduce(HeadsRdArgs a) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = a.D + 3 * (a.D / 2) + 4;
+  if (e >= n) return;
+  const float inv = a.scale ? 1.0f / a.scale[0] : 1.0f;
+  float sum = 0.f;
+  for (int p = 0; p < a.nsplit; ++p) sum += a.hpart[(int64_t)p * n + e];
+  sum *= inv;
+  if (e < a.D) a.dWs[e] = sum;
+  else if (e < a.D + 3 * (a.D / 2)) a.dWr[e - a.D] = sum;
+  else if (e < n - 1) a.dbr[e - a.D - 3 * (a.D / 2)] = sum;
+  else a.dbs[0] = sum;
+}
+
+// ------------------------------------------------------------------ host side
+static NetParams net_params(const fsn_mlp_desc& d, const NetGeom& G, const void* blob) {
+  NetParams p;
+  p.blob = static_cast<const char*>(blob);
+  p.aux_off = (int32_t)G.aux_off; p.aux_floats = G.aux_floats; p.stream_off = (int32_t)G.stream_off;
+  p.nph_density = G.nph_density; p.nph_full = G.nph_full;
+  p.n_layers = d.n_layers; p.skip_mask = d.skip_mask;
+  p.n_freqs_pos = d.n_freqs_pos; p.n_freqs_dir = d.n_freqs_dir;
+  return p;
+}
+
+int64_t fused_train_workspace_floats(const fsn_mlp_desc& d, int prec, int64_t n) {
+  FusedLayout F;
+  const char* why;
+  const int rc = make_fused_layout(d, prec, n, F, &why);
+  FSN_REQUIRE(rc == FSN_OK, rc, "training path: %s", why);
+  return F.total;
+}
+
+template <int NT, int PREC>
+static int launch_fwd(const TrainFwdArgs& a, unsigned grid, hipStream_t s) {
+  k_train_fwd<NT, PREC><<<grid, kThreads, 0, s>>>(a);
+  FSN_LAUNCH_CHECK("k_train_fwd");
+  return FSN_OK;
+}
+template <int NT, int PREC>
+static int launch_bwd(const TrainBwdArgs& a, unsigned grid, hipStream_t s) {
+  k_train_bwd<NT, PREC><<<grid, kThreads, 0, s>>>(a);
+  FSN_LAUNCH_CHECK("k_train_bwd");
+  return FSN_OK;
+}
+template <int MG, int BT>
+static int launch_wgrad(int prec, const WgArgs& a, int njobs, hipStream_t s) {
+  if (njobs == 0) return FSN_OK;
+  dim3 grid((unsigned)a.nsplit, (unsigned)njobs);
+  switch (prec) {
+    case 0: k_wgrad<MG, BT, 0><<<grid, kThreads, 0, s>>>(a); break;
+    case 1: k_wgrad<MG, BT, 1><<<grid, kThreads, 0, s>>>(a); break;
+    case 2: k_wgrad<MG, BT, 2><<<grid, kThreads, 0, s>>>(a); break;
+    default: k_wgrad<MG, BT, 3><<<grid, kThreads, 0, s>>>(a); break;
+  }
+  FSN_LAUNCH_CHECK("k_wgrad");
+  return FSN_OK;
+}
+
+int fused_train_fwd(const fsn_mlp_desc* d, int prec, const float* const* W, const float* const* b, const float* x,
+                    const float* dirs, const float* pos_mask, const float* dir_mask, int64_t n, float* ws, float* out,
+                    hipStream_t s) {
+  FusedLayout F;
+  const char* why;
+  int rc = make_fused_layout(*d, prec, n, F, &why);
+  FSN_REQUIRE(rc == FSN_OK, rc, "fsn_nerf_train_fwd: %s", why);
+  NetGeom G;
+  build_geom(*d, prec, G, &why);
+  FSN_REQUIRE(G.aux_floats <= kAuxCapFloats, FSN_E_UNSUPPORTED, "fsn_nerf_train_fwd: network too deep for the LDS aux area");
+  void* blob = ws + F.blob_f;
+  rc = fsn_mlp_pack(d, prec, W, b, blob, (fsn_stream_t)s);
+  if (rc != FSN_OK) return rc;
+  const int cus = fsn_device_cus();
+  if (cus <= 0) return FSN_E_HIP;
+  TrainFwdArgs a{net_params(*d, G, blob), x, dirs, pos_mask, dir_mask, n, out, ws, F.h, F.h_stride, F.bo, F.pe, F.de, F.D};
+  const unsigned grid = (unsigned)(F.T < cus ? F.T : cus);
+  const int key = (F.D == 256 ? 4 : 0) + prec;
+  switch (key) {
+    case 0: return launch_fwd<4, 0>(a, grid, s);
+    case 1: return launch_fwd<4, 1>(a, grid, s);
+    case 2: return launch_fwd<4, 2>(a, grid, s);
+    case 3: return launch_fwd<4, 3>(a, grid, s);
+    case 4: return launch_fwd<8, 0>(a, grid, s);
+    case 5: return launch_fwd<8, 1>(a, grid, s);
+    case 6: return launch_fwd<8, 2>(a, grid, s);
+    default: return launch_fwd<8, 3>(a, grid, s);
+  }
+}
+
+int fused_train_bwd(const fsn_mlp_desc* d, int prec, const float* const* W, int64_t n, float* ws, const float* out,
+                    const float* d_out, const float* grad_scale_dev, float* const* dW, float* const* db, hipStream_t s) {
+  FusedLayout F;
+  const char* why;
+  int rc = make_fused_layout(*d, prec, n, F, &why);
+  FSN_REQUIRE(rc == FSN_OK, rc, "fsn_nerf_train_bwd: %s", why);
+  NetGeom G;
+  build_geom(*d, prec, G, &why);
+  const int cus = fsn_device_cus();
+  if (cus <= 0) return FSN_E_HIP;
+  const int L = F.L, D = F.D, NT = F.NT;
+  // ---- transposed-weight stream
+  {
+    BwdPackArgs p{};
+    int u = 0, gi = 0;
+    p.W[gi] = W[L + 2]; p.ld[gi] = D + F.d_de; p.ks[gi] = NT / 2; p.unit0[gi] = u; u += 2 * NT * (NT / 2); ++gi;
+    p.W[gi] = W[L + 1]; p.ld[gi] = D; p.ks[gi] = NT; p.unit0[gi] = u; u += 2 * NT * NT; ++gi;
+    for (int l = L - 1; l >= 1; --l) {
+      const bool wide = (d->skip_mask >> (l - 1)) & 1u;
+      p.W[gi] = W[l]; p.ld[gi] = D + (wide ? F.d_pe : 0); p.ks[gi] = NT; p.unit0[gi] = u; u += 2 * NT * NT; ++gi;
+    }
+    p.n_gemm = gi; p.units_total = u; p.prec = prec; p.NT = NT;
+    FSN_REQUIRE(u == F.n_bwd_units, FSN_E_HIP, "internal: backward unit count");
+    const int64_t n_pieces = (int64_t)F.nph_bwd * kPhaseBytes / 16;
+    k_pack_bwd<<<(unsigned)((n_pieces + 255) / 256), 256, 0, s>>>(p, reinterpret_cast<char*>(ws + F.blob_b), n_pieces);
+    FSN_LAUNCH_CHECK("k_pack_bwd");
+  }
+  // ---- dgrad chain
+  {
+    TrainBwdArgs a{net_params(*d, G, ws + F.blob_f), reinterpret_cast<const char*>(ws + F.blob_b), F.nph_bwd, n, out, d_out,
+                   grad_scale_dev, ws, F.h, F.h_stride, F.bo, F.dhead, F.dbo, F.dp};
+    const unsigned grid = (unsigned)(F.T < cus ? F.T : cus);
+    const int key = (D == 256 ? 4 : 0) + prec;
+    switch (key) {
+      case 0: rc = launch_bwd<4, 0>(a, grid, s); break;
+      case 1: rc = launch_bwd<4, 1>(a, grid, s); break;
+      case 2: rc = launch_bwd<4, 2>(a, grid, s); break;
+      case 3: rc = launch_bwd<4, 3>(a, grid, s); break;
+      case 4: rc = launch_bwd<8, 0>(a, grid, s); break;
+      case 5: rc = launch_bwd<8, 1>(a, grid, s); break;
+      case 6: rc = launch_bwd<8, 2>(a, grid, s); break;
+      default: rc = launch_bwd<8, 3>(a, grid, s); break;
+    }
+    if (rc != FSN_OK) return rc;
+  }
+  // ---- wgrad jobs
+  WgArgs big{}, enc{}, br{}, bd{};
+  RdArgs rd{};
+  int nbig = 0, nenc = 0, nrd = 0;
+  float* part = ws + F.part;
+  const int64_t ns = F.nsplit;
+  auto H = [&](int i) { return ws + F.h + i * F.h_stride; };
+  auto dP = [&](int i) { return ws + F.dp + i * F.h_stride; };
+  auto add = [&](WgArgs& wa, int& cnt, const float* A, const float* B, int a_rows, int b_rows, bool bias, float* dWp, float* dbp,
+                 int ld, int col0, int mode, int n_freqs) {
+    WgJob& j = wa.job[cnt++];
+    j.A = A; j.B = B; j.b_rows = b_rows;
+    j.part = part; part += ns * a_rows * b_rows;
+    j.bpart = nullptr;
+    if (bias) { j.bpart = part; part += ns * a_rows; }
+    RdJob& r = rd.job[nrd++];
+    r.part = j.part; r.bpart = j.bpart; r.dW = dWp; r.db = dbp; r.a_rows = a_rows; r.b_rows = b_rows; r.ld = ld;
+    r.col0 = col0; r.mode = mode; r.n_freqs = n_freqs;
+  };
+  for (int l = 1; l < L; ++l) {
+    const bool wide = (d->skip_mask >> (l - 1)) & 1u;
+    add(big, nbig, dP(l), H(l - 1), D, D, true, dW[l], db[l], D + (wide ? F.d_pe : 0), 0, 0, 0);
+    if (wide) add(enc, nenc, dP(l), ws + F.pe, D, 64, false, dW[l], nullptr, D + F.d_pe, D, 1, d->n_freqs_pos);
+  }
+  add(big, nbig, dP(L), H(L - 1), D, D, true, dW[L + 1], db[L + 1], D, 0, 0, 0);
+  add(enc, nenc, dP(0), ws + F.pe, D, 64, true, dW[0], db[0], F.d_pe, 0, 1, d->n_freqs_pos);
+  int nbr = 0, nbd = 0;
+  add(br, nbr, ws + F.dbo, H(L), D / 2, D, true, dW[L + 2], db[L + 2], D + F.d_de, 0, 0, 0);
+  add(bd, nbd, ws + F.dbo, ws + F.de, D / 2, 32, false, dW[L + 2], nullptr, D + F.d_de, D, 2, d->n_freqs_dir);
+  FSN_REQUIRE(part - (ws + F.part) <= part_floats(*d, F.nsplit), FSN_E_HIP, "internal: wgrad partial area");
+  big.T = enc.T = br.T = bd.T = F.T;
+  big.nsplit = enc.nsplit = br.nsplit = bd.nsplit = F.nsplit;
+  if (D == 256) {
+    if ((rc = launch_wgrad<4, 4>(prec, big, nbig, s)) != FSN_OK) return rc;
+    if ((rc = launch_wgrad<4, 1>(prec, enc, nenc, s)) != FSN_OK) return rc;
+    if ((rc = launch_wgrad<2, 2>(prec, br, nbr, s)) != FSN_OK) return rc;
+    if ((rc = launch_wgrad<2, 1>(prec, bd, nbd, s)) != FSN_OK) return rc;
+  } else {
+    if ((rc = launch_wgrad<2, 1>(prec, big, nbig, s)) != FSN_OK) return rc;
+    if ((rc = launch_wgrad<2, 1>(prec, enc, nenc, s)) != FSN_OK) return rc;
+    if ((rc = launch_wgrad<1, 1>(prec, br, nbr, s)) != FSN_OK) return rc;
+    if ((rc = launch_wgrad<1, 1>(prec, bd, nbd, s)) != FSN_OK) return rc;
+  }
+  rd.nsplit = F.nsplit;
+  rd.scale = grad_scale_dev;
+  {
+    dim3 grid((unsigned)((D * D + 255) / 256), (unsigned)nrd);
+    k_wgrad_reduce<<<grid, 256, 0, s>>>(rd);
+    FSN_LAUNCH_CHECK("k_wgrad_reduce");
+  }
+  // ---- heads
+  {
+    HeadsArgs ha{H(L - 1), ws + F.bo, ws + F.dhead, ws + F.hpart, F.T, F.nsplit_heads};
+    if (D == 256) k_heads_wgrad<8><<<(unsigned)F.nsplit_heads, kThreads, 0, s>>>(ha);
+    else k_heads_wgrad<4><<<(unsigned)F.nsplit_heads, kThreads, 0, s>>>(ha);
+    FSN_LAUNCH_CHECK("k_heads_wgrad");
+    HeadsRdArgs hr{ws + F.hpart, F.nsplit_heads, D, grad_scale_dev, dW[L], db[L], dW[L + 3], db[L + 3]};
+    const int nn = D + 3 * (D / 2) + 4;
+    k_heads_reduce<<<(unsigned)((nn + 255) / 256), 256, 0, s>>>(hr);
+    FSN_LAUNCH_CHECK("k_heads_reduce");
+  }
+  return FSN_OK;
+}
+
+}  // namespace fsn

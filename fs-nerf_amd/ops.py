@@ -316,36 +316,47 @@ def _ptr_array(ts: Sequence[Tensor]):
     return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
 
 
-def nerf_train_fwd(desc: L.MlpDesc, weights: Sequence[Tensor], biases: Sequence[Tensor], x: Tensor, dirs: Tensor,
-                   pos_mask: Optional[Tensor], dir_mask: Optional[Tensor]):
-    """NeRF.forward keeping fp32 activations for the backward: -> (out [n,4], workspace)."""
+def nerf_train_fwd(desc: L.MlpDesc, prec: int, weights: Sequence[Tensor], biases: Sequence[Tensor], x: Tensor,
+                   dirs: Tensor, pos_mask: Optional[Tensor], dir_mask: Optional[Tensor]):
+    """NeRF.forward keeping what the backward needs: -> (out [n,4], workspace).  prec: L.FSN_PREC_* (MFMA path)
+    or L.FSN_PREC_FP32 (plain library GEMMs)."""
     x, d = _f32(x, "x").reshape(-1, 3), _f32(dirs, "dirs").reshape(-1, 3)
     n = x.shape[0]
     ws_ = [_f32(w.detach(), "weight") for w in weights]
     bs_ = [_f32(b.detach(), "bias") for b in biases]
-    nfl = L.lib().fsn_nerf_train_workspace_floats(C.byref(desc), n)
-    if nfl < 0:
-        L.check(int(nfl), "fsn_nerf_train_workspace_floats")
-    work = torch.empty(max(int(nfl), 1), device=x.device, dtype=torch.float32)
-    out = torch.empty(n, 4, device=x.device, dtype=torch.float32)
-    pm = None if pos_mask is None else _f32(pos_mask, "pos_mask")
-    dm = None if dir_mask is None else _f32(dir_mask, "dir_mask")
     with torch.cuda.device(x.device):
-        L.check(L.lib().fsn_nerf_train_fwd(C.byref(desc), _ptr_array(ws_), _ptr_array(bs_), _p(x), _p(d), _p(pm), _p(dm),
-                                           n, _p(work), _p(out), _stream()), "fsn_nerf_train_fwd")
+        nfl = L.lib().fsn_nerf_train_workspace_floats(C.byref(desc), prec, n)
+        if nfl < 0:
+            L.check(int(nfl), "fsn_nerf_train_workspace_floats")
+        work = torch.empty(max(int(nfl), 1), device=x.device, dtype=torch.float32)
+        out = torch.empty(n, 4, device=x.device, dtype=torch.float32)
+        pm = None if pos_mask is None else _f32(pos_mask, "pos_mask")
+        dm = None if dir_mask is None else _f32(dir_mask, "dir_mask")
+        L.check(L.lib().fsn_nerf_train_fwd(C.byref(desc), prec, _ptr_array(ws_), _ptr_array(bs_), _p(x), _p(d), _p(pm),
+                                           _p(dm), n, _p(work), _p(out), _stream()), "fsn_nerf_train_fwd")
     return out, work
 
 
-def nerf_train_bwd(desc: L.MlpDesc, weights: Sequence[Tensor], work: Tensor, out: Tensor, d_out: Tensor):
+def grad_scale_for(d_out: Tensor) -> Tensor:
+    """Power of two that brings max|d_out| to ~2^10 (device scalar, no host sync): the fp16 MFMA modes of the
+    backward multiply d_out by it on entry and divide the gradients by it at the end."""
+    amax = d_out.detach().abs().amax().to(torch.float32)
+    e = torch.floor(torch.log2(1024.0 / amax))
+    e = torch.nan_to_num(e, nan=0.0, posinf=0.0, neginf=0.0).clamp(-40.0, 60.0)
+    return torch.exp2(e).reshape(1)
+
+
+def nerf_train_bwd(desc: L.MlpDesc, prec: int, weights: Sequence[Tensor], work: Tensor, out: Tensor, d_out: Tensor):
     """-> (d_weights, d_biases) lists in state_dict order."""
     ws_ = [_f32(w.detach(), "weight") for w in weights]
     d_out = _f32(d_out, "d_out").reshape(-1, 4)
     n = d_out.shape[0]
     dW = [torch.empty_like(w) for w in ws_]
     db = [torch.empty(w.shape[0], device=w.device, dtype=torch.float32) for w in ws_]
+    scale = grad_scale_for(d_out) if prec in (L.FSN_PREC_FP16X3, L.FSN_PREC_FP16) else None
     with torch.cuda.device(work.device):
-        L.check(L.lib().fsn_nerf_train_bwd(C.byref(desc), _ptr_array(ws_), n, _p(work), _p(out), _p(d_out),
-                                           _ptr_array(dW), _ptr_array(db), _stream()), "fsn_nerf_train_bwd")
+        L.check(L.lib().fsn_nerf_train_bwd(C.byref(desc), prec, _ptr_array(ws_), n, _p(work), _p(out), _p(d_out),
+                                           _p(scale), _ptr_array(dW), _ptr_array(db), _stream()), "fsn_nerf_train_bwd")
     return dW, db
 
 

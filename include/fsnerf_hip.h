@@ -172,21 +172,27 @@ int fsn_occlusion_reg_fwd(const float* sigmas, const float* t_vals, const int64_
                           int64_t n_rays, float a, float b, int func, float* ray_sums, float* out,
                           fsn_stream_t stream);
 
-/* f1 (first version): the training step around the path.        src/run-nerf.py:243-285, models.py:111-143
- * "Plain" formulation: fp32 activations are kept in a caller-provided workspace, the Linear layers are
- * library GEMMs (rocBLAS sgemm, bound with dlopen at first use), everything else HIP kernels.  Exact fp32
- * gradients; the rendering path does not use these entry points.
+/* f1: the training step around the path.                         src/run-nerf.py:243-285, models.py:111-143
+ * NeRF.forward keeping what its backward needs in a caller-provided workspace, and that backward (gradients of
+ * every parameter; sample positions / directions receive none on this path).
+ *   prec 0..3 (FSN_PREC_*): the MFMA path.  Forward = the inference kernel with fp32 activations saved in tiles of
+ *     128 samples; backward = register-resident dgrad chain on transposed weights + split-K wgrad GEMMs over all
+ *     samples (csrc/train_fused.hip).  grad_scale: DEVICE pointer to one float, a power of two that d_out is
+ *     multiplied by on entry (results are divided by it again) so that fp16 parts keep small gradients; null = 1.
+ *   prec FSN_PREC_FP32: the plain formulation, fp32 library GEMMs (rocBLAS sgemm, bound with dlopen at first
+ *     use) layer by layer; the reference the MFMA path is tested against.  grad_scale must be null.
  *   weights / biases / d_weights / d_biases: HOST arrays of n_layers+4 DEVICE pointers in state_dict order
  *   (layers.0.., sigma, connection, branch, rgb); gradients are overwritten, not accumulated.
- *   workspace: fsn_nerf_train_workspace_floats(desc, n) floats, written by _fwd, consumed (and scribbled on)
- *   by _bwd; out / d_out [n,4] = [rgb, sigma]. */
-int64_t fsn_nerf_train_workspace_floats(const fsn_mlp_desc* desc, int64_t n);
-int fsn_nerf_train_fwd(const fsn_mlp_desc* desc, const float* const* weights, const float* const* biases,
+ *   workspace: fsn_nerf_train_workspace_floats(desc, prec, n) floats, written by _fwd, consumed (and scribbled on)
+ *   by _bwd with the same desc / prec / n; out / d_out [n,4] = [rgb, sigma]. */
+#define FSN_PREC_FP32 4
+int64_t fsn_nerf_train_workspace_floats(const fsn_mlp_desc* desc, int prec, int64_t n);
+int fsn_nerf_train_fwd(const fsn_mlp_desc* desc, int prec, const float* const* weights, const float* const* biases,
                        const float* x, const float* dirs, const float* pos_mask, const float* dir_mask,
                        int64_t n, float* workspace, float* out, fsn_stream_t stream);
-int fsn_nerf_train_bwd(const fsn_mlp_desc* desc, const float* const* weights, int64_t n, float* workspace,
-                       const float* out, const float* d_out, float* const* d_weights, float* const* d_biases,
-                       fsn_stream_t stream);
+int fsn_nerf_train_bwd(const fsn_mlp_desc* desc, int prec, const float* const* weights, int64_t n, float* workspace,
+                       const float* out, const float* d_out, const float* grad_scale, float* const* d_weights,
+                       float* const* d_biases, fsn_stream_t stream);
 /* backward of fsn_composite_packed_fwd with respect to sigmas and rgbs, given dL/dcolors [R,3] and
  * (optional) dL/dopacity [R]; dL/ddepth is not propagated. */
 int fsn_composite_packed_bwd(const float* sigmas, const float* rgbs, const float* t_starts, const float* t_ends,
