@@ -38,22 +38,32 @@ struct FusedLayout {
   int64_t T;  // sample tiles
   int64_t blob_f, blob_b;
   int64_t pe, de, h, h_stride, bo, dhead, dbo, dp, part, hpart, total;  // float offsets
-  int nsplit, nsplit_heads, n_bwd_units, nph_bwd;
+  int64_t mask, mask_stride;  // ReLU sign bits: [L hidden layers + branch][tile][4 lane groups][128 samples] x 2 words
+  int nsplit[4], nsplit_heads, n_bwd_units, nph_bwd;
   int64_t blob_f_bytes;
 };
 
-static int n_big_jobs(const fsn_mlp_desc& d) { return d.n_layers + 1; }  // layers 1..L-1, connection, branch
-
-static int64_t part_floats(const fsn_mlp_desc& d, int nsplit) {
-  const int64_t D = d.d_hidden, L = d.n_layers;
-  int64_t per = 0;
-  per += (L - 1 + 1) * (D * D + D);                                   // hidden 1..L-1, connection
-  int n_pe = 1;
-  for (int l = 1; l < L; ++l) n_pe += (d.skip_mask >> (l - 1)) & 1u;
-  per += n_pe * (D * 64 + D);                                          // encoding columns of layer 0 / wide layers
-  per += (D / 2) * D + D / 2;                                          // branch (features)
-  per += (D / 2) * 32 + D / 2;                                         // branch (direction encoding)
-  return per * nsplit;
+// The four wgrad launches (jobs of one shape each) and their split-K counts: every launch should put about one
+// workgroup on every CU.
+enum { WG_BIG = 0, WG_ENC = 1, WG_BR = 2, WG_BD = 3 };
+static int n_jobs_of(const fsn_mlp_desc& d, int kind) {
+  if (kind == WG_BIG) return d.n_layers;  // layers 1..L-1, connection
+  if (kind == WG_ENC) {
+    int n = 1;
+    for (int l = 1; l < d.n_layers; ++l) n += (d.skip_mask >> (l - 1)) & 1u;
+    return n;
+  }
+  return 1;
+}
+static int split_of(const fsn_mlp_desc& d, int kind, int cus, int64_t T) {
+  int64_t ns = cus / n_jobs_of(d, kind);
+  if (ns > T) ns = T;
+  return ns < 1 ? 1 : (int)ns;
+}
+static int64_t part_floats(const fsn_mlp_desc& d, const int nsplit[4]) {
+  const int64_t D = d.d_hidden;
+  return (int64_t)n_jobs_of(d, WG_BIG) * nsplit[WG_BIG] * (D * D + D) + (int64_t)n_jobs_of(d, WG_ENC) * nsplit[WG_ENC] * (D * 64 + D) +
+         (int64_t)nsplit[WG_BR] * ((D / 2) * D + D / 2) + (int64_t)nsplit[WG_BD] * ((D / 2) * 32 + D / 2);
 }
 
 static int make_fused_layout(const fsn_mlp_desc& d, int prec, int64_t n, FusedLayout& F, const char** why) {
@@ -65,11 +75,7 @@ static int make_fused_layout(const fsn_mlp_desc& d, int prec, int64_t n, FusedLa
   F.T = (n + kTC - 1) / kTC;
   int cus = fsn_device_cus();
   if (cus <= 0) cus = 256;  // sizing query without a device
-  int64_t ns = cus / n_big_jobs(d);
-  if (ns < 1) ns = 1;
-  if (ns > F.T) ns = F.T;
-  if (ns < 1) ns = 1;
-  F.nsplit = (int)ns;
+  for (int k = 0; k < 4; ++k) F.nsplit[k] = split_of(d, k, cus, F.T);
   F.nsplit_heads = (int)(F.T < cus ? (F.T > 0 ? F.T : 1) : cus);
   const int NT = F.NT;
   F.n_bwd_units = NT * NT + 2 * NT * NT + (F.L - 1) * 2 * NT * NT;
@@ -86,6 +92,8 @@ static int make_fused_layout(const fsn_mlp_desc& d, int prec, int64_t n, FusedLa
   F.h_stride = T * D * kTC;
   F.h = o; o += (F.L + 1) * F.h_stride;  // H_0..H_{L-1}, connection output
   F.bo = o; o += T * (D / 2) * kTC;
+  F.mask_stride = T * 4 * kTC * 2;
+  F.mask = o; o += (F.L + 1) * F.mask_stride;
   F.dhead = o; o += T * 4 * kTC;
   F.dbo = o; o += T * (D / 2) * kTC;
   F.dp = o; o += (F.L + 1) * F.h_stride;  // dPre_0..dPre_{L-1}, d(connection output)
@@ -98,20 +106,40 @@ static int make_fused_layout(const fsn_mlp_desc& d, int prec, int64_t n, FusedLa
 // ------------------------------------------------------------------ forward with saved activations
 struct FwdSaver {
   static constexpr bool kSave = true;
+  // Stores the fp32 values (T-layout) and, for ReLU layers, their sign bits: bit 8 tp + j of this lane's 64-bit
+  // word <=> element j of output pair tp is > 0.  The dgrad chain reads only the bits.
   struct Hook {
     static constexpr bool kZeroInit = false;
     float* p;
+    uint32_t* mk;  // this lane's 2 mask words, or null (layer without activation)
+    int last_tp;
+    uint32_t b0 = 0, b1 = 0;
     __device__ __forceinline__ void pre(int) {}
     __device__ __forceinline__ void post(int tp, float (&v)[8]) {
+      uint32_t b = 0;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) p[(32 * tp + 16 * (j >> 2) + (j & 3)) * kTC] = v[j];
+      for (int j = 0; j < 8; ++j) {
+        p[(32 * tp + 16 * (j >> 2) + (j & 3)) * kTC] = v[j];
+        b |= (v[j] > 0.f ? 1u : 0u) << j;
+      }
+      if (tp < 4) b0 |= b << (8 * (tp & 3));
+      else b1 |= b << (8 * (tp & 3));
+      if (tp == last_tp && mk) {
+        mk[0] = b0;
+        mk[1] = b1;
+      }
     }
   };
   float* h0;  // this lane's column, row 4g, of H_0's tile
   int64_t hstride;
   float *bo, *pe, *de;
-  __device__ __forceinline__ Hook hidden(int l) const { return Hook{h0 + l * hstride}; }
-  __device__ __forceinline__ Hook branch() const { return Hook{bo}; }
+  uint32_t* mk0;  // this lane's mask words of layer 0
+  int64_t mstride;
+  int n_layers, nt;
+  __device__ __forceinline__ Hook hidden(int l) const {
+    return Hook{h0 + l * hstride, l < n_layers ? mk0 + l * mstride : nullptr, nt - 1};
+  }
+  __device__ __forceinline__ Hook branch() const { return Hook{bo, mk0 + n_layers * mstride, nt / 2 - 1}; }
   __device__ __forceinline__ float* enc_pos(int) const { return pe; }
   __device__ __forceinline__ float* enc_dir(int) const { return de; }
 };
@@ -122,7 +150,7 @@ struct TrainFwdArgs {
   int64_t n;
   float* out;
   float* ws;
-  int64_t off_h, h_stride, off_bo, off_pe, off_de;
+  int64_t off_h, h_stride, off_bo, off_pe, off_de, off_mask, mask_stride;
   int32_t D;
 };
 
@@ -164,6 +192,10 @@ __global__ __launch_bounds__(kThreads) void k_train_fwd(TrainFwdArgs a) {
     sv.bo = a.ws + a.off_bo + (tile * (D / 2) + 4 * g) * kTC + col;
     sv.pe = a.ws + a.off_pe + (tile * 64 + 8 * g) * kTC + col;
     sv.de = a.ws + a.off_de + (tile * 32 + 8 * g) * kTC + col;
+    sv.mk0 = reinterpret_cast<uint32_t*>(a.ws + a.off_mask) + ((tile * 4 + g) * kTC + col) * 2;
+    sv.mstride = a.mask_stride;
+    sv.n_layers = net.n_layers;
+    sv.nt = NT;
     float sigma, rgb[3] = {0.f, 0.f, 0.f};
     mlp_tile<NT, PREC, true>(st, net, src, ring, sigma, rgb, sv);
     if (lane < 16 && s < a.n) {
@@ -231,15 +263,11 @@ struct BwdStoreHook {
 template <bool ADD_SIGMA>
 struct BwdMaskHook {
   static constexpr bool kZeroInit = true;
-  const float* h;     // saved activation of the layer whose pre-activation gradient this is
+  uint32_t b0, b1;    // sign bits of the layer whose pre-activation gradient this is (FwdSaver::Hook)
   float* d;           // dPre destination
   float dsig;         // d sigma of this lane's sample
   const float* wsig;  // LDS: w_sigma + 4g
-  float hv[8];
-  __device__ __forceinline__ void pre(int tp) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) hv[j] = h[(32 * tp + 16 * (j >> 2) + (j & 3)) * kTC];
-  }
+  __device__ __forceinline__ void pre(int) {}
   __device__ __forceinline__ void post(int tp, float (&v)[8]) {
     if (ADD_SIGMA) {  // sigma = w_sigma . h_{L-1} + b (models.py:127)
       const f32x4 w0 = *reinterpret_cast<const f32x4*>(wsig + 32 * tp);
@@ -250,9 +278,10 @@ struct BwdMaskHook {
         v[4 + j] = v[4 + j] + dsig * w1[j];
       }
     }
+    const uint32_t bits = (tp < 4 ? b0 : b1) >> (8 * (tp & 3));
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      v[j] = hv[j] > 0.f ? v[j] : 0.f;
+      v[j] = ((bits >> j) & 1u) ? v[j] : 0.f;
       d[(32 * tp + 16 * (j >> 2) + (j & 3)) * kTC] = v[j];
     }
   }
@@ -265,7 +294,7 @@ struct TrainBwdArgs {
   int64_t n;
   const float *out, *d_out, *scale;
   float* ws;
-  int64_t off_h, h_stride, off_bo, off_dhead, off_dbo, off_dp;
+  int64_t off_h, h_stride, off_bo, off_dhead, off_dbo, off_dp, off_mask, mask_stride;
 };
 
 template <int NT, int PREC>
@@ -308,8 +337,9 @@ __global__ __launch_bounds__(kThreads) void k_train_bwd(TrainBwdArgs a) {
     const int64_t lane_off = (tile * D + 4 * g) * kTC + col;         // row 4g of a D-row tile
     const int64_t lane_off_h = (tile * (D / 2) + 4 * g) * kTC + col;  // ... of a D/2-row tile
     Frag A[NT], B[NT];
+    const uint32_t* mk = reinterpret_cast<const uint32_t*>(a.ws + a.off_mask) + ((tile * 4 + g) * kTC + col) * 2;
     {  // branch output: d Bo = W_rgb^T dz, masked by Bo > 0 (models.py:133-134), VALU
-      const float* bo = a.ws + a.off_bo + lane_off_h;
+      const uint32_t bbits = mk[L * a.mask_stride];
       float* dbo = a.ws + a.off_dbo + lane_off_h;
       const float* wr = net.aux + (L + 3) * D + 4 * g;
 #pragma unroll
@@ -324,7 +354,7 @@ __global__ __launch_bounds__(kThreads) void k_train_bwd(TrainBwdArgs a) {
           for (int j = 0; j < 4; ++j) {
             const int off = (32 * ks + 16 * hh + j) * kTC;
             const float val = (dz[0] * w0[j] + dz[1] * w1[j]) + dz[2] * w2[j];
-            const float r = bo[off] > 0.f ? val : 0.f;
+            const float r = ((bbits >> (8 * ks + 4 * hh + j)) & 1u) ? val : 0.f;
             dbo[off] = r;
             v[4 * hh + j] = r;
           }
@@ -338,7 +368,8 @@ __global__ __launch_bounds__(kThreads) void k_train_bwd(TrainBwdArgs a) {
     }
     {  // d h_{L-1} = W_conn^T d feat + d sigma w_sigma, masked by h_{L-1} > 0
       BwdMaskHook<true> hk;
-      hk.h = a.ws + a.off_h + (L - 1) * a.h_stride + lane_off;
+      hk.b0 = mk[(L - 1) * a.mask_stride];
+      hk.b1 = mk[(L - 1) * a.mask_stride + 1];
       hk.d = a.ws + a.off_dp + (L - 1) * a.h_stride + lane_off;
       hk.dsig = dsig;
       hk.wsig = net.aux + (L + 2) * D + 4 * g;
@@ -348,13 +379,15 @@ __global__ __launch_bounds__(kThreads) void k_train_bwd(TrainBwdArgs a) {
     for (int l = L - 1; l >= 1; l -= 2) {
       {
         BwdMaskHook<false> hk;
-        hk.h = a.ws + a.off_h + (l - 1) * a.h_stride + lane_off;
+        hk.b0 = mk[(l - 1) * a.mask_stride];
+        hk.b1 = mk[(l - 1) * a.mask_stride + 1];
         hk.d = a.ws + a.off_dp + (l - 1) * a.h_stride + lane_off;
         gemm_layer<PREC, NT, NT, 0, EPI_CVT>(st, net, 0, B, none, A, heads, ring, g, hk);
       }
       if (l - 1 >= 1) {
         BwdMaskHook<false> hk;
-        hk.h = a.ws + a.off_h + (l - 2) * a.h_stride + lane_off;
+        hk.b0 = mk[(l - 2) * a.mask_stride];
+        hk.b1 = mk[(l - 2) * a.mask_stride + 1];
         hk.d = a.ws + a.off_dp + (l - 2) * a.h_stride + lane_off;
         gemm_layer<PREC, NT, NT, 0, EPI_CVT>(st, net, 0, A, none, B, heads, ring, g, hk);
       }
@@ -530,10 +563,10 @@ struct RdJob {
   float* dW;
   float* db;
   int32_t a_rows, b_rows, ld, col0, mode, n_freqs;  // mode 0: column = col0 + c; 1/2: position/direction slots
+  int32_t nsplit;
 };
 struct RdArgs {
   RdJob job[2 * kMaxLayers + 4];
-  int32_t nsplit;
   const float* scale;
 };
 
@@ -555,13 +588,13 @@ __global__ void k_wgrad_reduce(RdArgs a) {
     }
     if (colo >= 0) {
       float sum = 0.f;
-      for (int p = 0; p < a.nsplit; ++p) sum += jb.part[(int64_t)p * tot + e];
+      for (int p = 0; p < jb.nsplit; ++p) sum += jb.part[(int64_t)p * tot + e];
       jb.dW[(int64_t)row * jb.ld + colo] = sum * inv;
     }
   }
   if (jb.bpart && e < jb.a_rows) {
     float sum = 0.f;
-    for (int p = 0; p < a.nsplit; ++p) sum += jb.bpart[(int64_t)p * jb.a_rows + e];
+    for (int p = 0; p < jb.nsplit; ++p) sum += jb.bpart[(int64_t)p * jb.a_rows + e];
     jb.db[e] = sum * inv;
   }
 }
@@ -715,7 +748,8 @@ int fused_train_fwd(const fsn_mlp_desc* d, int prec, const float* const* W, cons
   if (rc != FSN_OK) return rc;
   const int cus = fsn_device_cus();
   if (cus <= 0) return FSN_E_HIP;
-  TrainFwdArgs a{net_params(*d, G, blob), x, dirs, pos_mask, dir_mask, n, out, ws, F.h, F.h_stride, F.bo, F.pe, F.de, F.D};
+  TrainFwdArgs a{net_params(*d, G, blob), x, dirs, pos_mask, dir_mask, n, out, ws, F.h, F.h_stride, F.bo, F.pe, F.de,
+                 F.mask, F.mask_stride, F.D};
   const unsigned grid = (unsigned)(F.T < cus ? F.T : cus);
   const int key = (F.D == 256 ? 4 : 0) + prec;
   switch (key) {
@@ -760,7 +794,7 @@ int fused_train_bwd(const fsn_mlp_desc* d, int prec, const float* const* W, int6
   // ---- dgrad chain
   {
     TrainBwdArgs a{net_params(*d, G, ws + F.blob_f), reinterpret_cast<const char*>(ws + F.blob_b), F.nph_bwd, n, out, d_out,
-                   grad_scale_dev, ws, F.h, F.h_stride, F.bo, F.dhead, F.dbo, F.dp};
+                   grad_scale_dev, ws, F.h, F.h_stride, F.bo, F.dhead, F.dbo, F.dp, F.mask, F.mask_stride};
     const unsigned grid = (unsigned)(F.T < cus ? F.T : cus);
     const int key = (D == 256 ? 4 : 0) + prec;
     switch (key) {
@@ -776,37 +810,38 @@ int fused_train_bwd(const fsn_mlp_desc* d, int prec, const float* const* W, int6
     if (rc != FSN_OK) return rc;
   }
   // ---- wgrad jobs
-  WgArgs big{}, enc{}, br{}, bd{};
+  WgArgs wa[4] = {};
+  int cnt[4] = {0, 0, 0, 0};
   RdArgs rd{};
-  int nbig = 0, nenc = 0, nrd = 0;
+  int nrd = 0;
   float* part = ws + F.part;
-  const int64_t ns = F.nsplit;
   auto H = [&](int i) { return ws + F.h + i * F.h_stride; };
   auto dP = [&](int i) { return ws + F.dp + i * F.h_stride; };
-  auto add = [&](WgArgs& wa, int& cnt, const float* A, const float* B, int a_rows, int b_rows, bool bias, float* dWp, float* dbp,
-                 int ld, int col0, int mode, int n_freqs) {
-    WgJob& j = wa.job[cnt++];
+  auto add = [&](int kind, const float* A, const float* B, int a_rows, int b_rows, bool bias, float* dWp, float* dbp, int ld,
+                 int col0, int mode, int n_freqs) {
+    const int64_t ns = F.nsplit[kind];
+    WgJob& j = wa[kind].job[cnt[kind]++];
     j.A = A; j.B = B; j.b_rows = b_rows;
     j.part = part; part += ns * a_rows * b_rows;
     j.bpart = nullptr;
     if (bias) { j.bpart = part; part += ns * a_rows; }
     RdJob& r = rd.job[nrd++];
     r.part = j.part; r.bpart = j.bpart; r.dW = dWp; r.db = dbp; r.a_rows = a_rows; r.b_rows = b_rows; r.ld = ld;
-    r.col0 = col0; r.mode = mode; r.n_freqs = n_freqs;
+    r.col0 = col0; r.mode = mode; r.n_freqs = n_freqs; r.nsplit = (int)ns;
   };
   for (int l = 1; l < L; ++l) {
     const bool wide = (d->skip_mask >> (l - 1)) & 1u;
-    add(big, nbig, dP(l), H(l - 1), D, D, true, dW[l], db[l], D + (wide ? F.d_pe : 0), 0, 0, 0);
-    if (wide) add(enc, nenc, dP(l), ws + F.pe, D, 64, false, dW[l], nullptr, D + F.d_pe, D, 1, d->n_freqs_pos);
+    add(WG_BIG, dP(l), H(l - 1), D, D, true, dW[l], db[l], D + (wide ? F.d_pe : 0), 0, 0, 0);
+    if (wide) add(WG_ENC, dP(l), ws + F.pe, D, 64, false, dW[l], nullptr, D + F.d_pe, D, 1, d->n_freqs_pos);
   }
-  add(big, nbig, dP(L), H(L - 1), D, D, true, dW[L + 1], db[L + 1], D, 0, 0, 0);
-  add(enc, nenc, dP(0), ws + F.pe, D, 64, true, dW[0], db[0], F.d_pe, 0, 1, d->n_freqs_pos);
-  int nbr = 0, nbd = 0;
-  add(br, nbr, ws + F.dbo, H(L), D / 2, D, true, dW[L + 2], db[L + 2], D + F.d_de, 0, 0, 0);
-  add(bd, nbd, ws + F.dbo, ws + F.de, D / 2, 32, false, dW[L + 2], nullptr, D + F.d_de, D, 2, d->n_freqs_dir);
+  add(WG_BIG, dP(L), H(L - 1), D, D, true, dW[L + 1], db[L + 1], D, 0, 0, 0);
+  add(WG_ENC, dP(0), ws + F.pe, D, 64, true, dW[0], db[0], F.d_pe, 0, 1, d->n_freqs_pos);
+  add(WG_BR, ws + F.dbo, H(L), D / 2, D, true, dW[L + 2], db[L + 2], D + F.d_de, 0, 0, 0);
+  add(WG_BD, ws + F.dbo, ws + F.de, D / 2, 32, false, dW[L + 2], nullptr, D + F.d_de, D, 2, d->n_freqs_dir);
   FSN_REQUIRE(part - (ws + F.part) <= part_floats(*d, F.nsplit), FSN_E_HIP, "internal: wgrad partial area");
-  big.T = enc.T = br.T = bd.T = F.T;
-  big.nsplit = enc.nsplit = br.nsplit = bd.nsplit = F.nsplit;
+  for (int k = 0; k < 4; ++k) { wa[k].T = F.T; wa[k].nsplit = F.nsplit[k]; }
+  const WgArgs &big = wa[WG_BIG], &enc = wa[WG_ENC], &br = wa[WG_BR], &bd = wa[WG_BD];
+  const int nbig = cnt[WG_BIG], nenc = cnt[WG_ENC], nbr = cnt[WG_BR], nbd = cnt[WG_BD];
   if (D == 256) {
     if ((rc = launch_wgrad<4, 4>(prec, big, nbig, s)) != FSN_OK) return rc;
     if ((rc = launch_wgrad<4, 1>(prec, enc, nenc, s)) != FSN_OK) return rc;
@@ -818,7 +853,6 @@ int fused_train_bwd(const fsn_mlp_desc* d, int prec, const float* const* W, int6
     if ((rc = launch_wgrad<1, 1>(prec, br, nbr, s)) != FSN_OK) return rc;
     if ((rc = launch_wgrad<1, 1>(prec, bd, nbd, s)) != FSN_OK) return rc;
   }
-  rd.nsplit = F.nsplit;
   rd.scale = grad_scale_dev;
   {
     dim3 grid((unsigned)((D * D + 255) / 256), (unsigned)nrd);
