@@ -107,13 +107,11 @@ static int make_fused_layout(const fsn_mlp_desc& d, int prec, int64_t n, FusedLa
 struct FwdSaver {
   static constexpr bool kSave = true;
   // Stores the fp32 values (T-layout) and, for ReLU layers, their sign bits: bit 8 tp + j of this lane's 64-bit
-  // word <=> element j of output pair tp is > 0.  The dgrad chain reads only the bits.
+  // word (byte tp, bit j) <=> element j of output pair tp is > 0.  The dgrad chain reads only the bits.
   struct Hook {
     static constexpr bool kZeroInit = false;
     float* p;
-    uint32_t* mk;  // this lane's 2 mask words, or null (layer without activation)
-    int last_tp;
-    uint32_t b0 = 0, b1 = 0;
+    uint8_t* mk;  // this lane's 8 mask bytes (one per output pair), or null (layer without activation)
     __device__ __forceinline__ void pre(int) {}
     __device__ __forceinline__ void post(int tp, float (&v)[8]) {
       uint32_t b = 0;
@@ -122,12 +120,7 @@ struct FwdSaver {
         p[(32 * tp + 16 * (j >> 2) + (j & 3)) * kTC] = v[j];
         b |= (v[j] > 0.f ? 1u : 0u) << j;
       }
-      if (tp < 4) b0 |= b << (8 * (tp & 3));
-      else b1 |= b << (8 * (tp & 3));
-      if (tp == last_tp && mk) {
-        mk[0] = b0;
-        mk[1] = b1;
-      }
+      if (mk) mk[tp] = (uint8_t)b;  // byte stores: accumulating the 64-bit word in registers tips the x3 modes into scratch
     }
   };
   float* h0;  // this lane's column, row 4g, of H_0's tile
@@ -135,11 +128,11 @@ struct FwdSaver {
   float *bo, *pe, *de;
   uint32_t* mk0;  // this lane's mask words of layer 0
   int64_t mstride;
-  int n_layers, nt;
+  int n_layers;
   __device__ __forceinline__ Hook hidden(int l) const {
-    return Hook{h0 + l * hstride, l < n_layers ? mk0 + l * mstride : nullptr, nt - 1};
+    return Hook{h0 + l * hstride, l < n_layers ? reinterpret_cast<uint8_t*>(mk0 + l * mstride) : nullptr};
   }
-  __device__ __forceinline__ Hook branch() const { return Hook{bo, mk0 + n_layers * mstride, nt / 2 - 1}; }
+  __device__ __forceinline__ Hook branch() const { return Hook{bo, reinterpret_cast<uint8_t*>(mk0 + n_layers * mstride)}; }
   __device__ __forceinline__ float* enc_pos(int) const { return pe; }
   __device__ __forceinline__ float* enc_dir(int) const { return de; }
 };
@@ -195,7 +188,6 @@ __global__ __launch_bounds__(kThreads) void k_train_fwd(TrainFwdArgs a) {
     sv.mk0 = reinterpret_cast<uint32_t*>(a.ws + a.off_mask) + ((tile * 4 + g) * kTC + col) * 2;
     sv.mstride = a.mask_stride;
     sv.n_layers = net.n_layers;
-    sv.nt = NT;
     float sigma, rgb[3] = {0.f, 0.f, 0.f};
     mlp_tile<NT, PREC, true>(st, net, src, ring, sigma, rgb, sv);
     if (lane < 16 && s < a.n) {
