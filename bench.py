@@ -20,6 +20,11 @@ The JSON line also carries
                  rocprofv3 PMC pass (profiles/), or null;
   cpu_baseline - the CPU oracle (PyTorch CPU ops, same operator sequence as the reference) timed on
                  this box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+
+`--workload train` times the TRAINING step instead (BASELINE.json configs[3]): forward-facing
+LLFF-style scene, 8 views of 378x504 (focal 407.6), NDC rays, near 0 / far 1, 64+128 samples, one 8x256 NeRF,
+4096 rays per rank and step, step = ray batch -> render_rays(train=True) -> MSE -> backward -> ONE all-reduce of
+the flat fp32 gradient bucket (RCCL) -> Adam -> ExponentialDecay; metric = trained rays/sec over all ranks.
 """
 import argparse
 import json
@@ -101,14 +106,113 @@ def cpu_baseline(target_s=15.0):
                       f"(PyTorch CPU fp32), {t:.1f} s"}
 
 
+# ---------------------------------------------------------------- training workload (configs[3])
+T_H, T_W, T_FOCAL, T_RAYS = 378, 504, 407.6, 4096  # LLFF images_8 geometry
+FLOP_PER_RAY_TRAIN = S * FLOP_DENSITY + 3 * (S + NI) * FLOP_FULL  # density pass (no grad) + fwd + dgrad + wgrad
+
+
+def train_poses():
+    """8 cameras on a 3x3-minus-centre planar grid at z = 0 looking down -z (forward-facing)."""
+    out = []
+    for iy in (-1, 0, 1):
+        for ix in (-1, 0, 1):
+            if ix == 0 and iy == 0:
+                continue
+            p = torch.eye(4)
+            p[0, 3], p[1, 3] = 0.25 * ix, 0.25 * iy
+            out.append(p)
+    return out
+
+
+def train_main(args, rank, world, dev, dist, backend):
+    from fs_nerf_amd import ops, shard
+    from fs_nerf_amd.core.models import NeRF
+    from fs_nerf_amd.core.scheduler import ExponentialDecay
+    from fs_nerf_amd.render import rendering as Rm
+    from fs_nerf_amd.utils import utilities as U
+    torch.manual_seed(42)  # identical replicas on every rank
+    model = NeRF(3, 3, 8, 256, (4,), precision=args.precision, pos_fn={"n_freqs": 10, "log_space": True},
+                 dir_fn={"n_freqs": 4, "log_space": True})
+    with torch.no_grad():
+        model.sigma.weight.mul_(64.0)
+        model.sigma.bias.add_(3.0)
+    model.to(dev).train()
+    est = Rm.StratifiedEstimator(0.0, 1.0, S, NI).train()  # NDC: near 0, far 1 (llff.py:51-53)
+    est.generator = torch.Generator(device=dev).manual_seed(1000 + rank)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4)
+    sched = ExponentialDecay(opt, 10000, 5e-4, r=0.1)
+    ro, rd = [], []
+    for pose in train_poses():  # dataset ray precompute on the device (llff.py:59-90)
+        o, d = U.get_rays(pose, (T_H, T_W, T_FOCAL), dev)
+        o, d = U.to_ndc(o.reshape(-1, 3), d.reshape(-1, 3), (T_H, T_W, T_FOCAL), 1.0)
+        ro.append(o)
+        rd.append(d)
+    ro, rd = torch.cat(ro), torch.cat(rd)
+    gt = torch.rand(ro.shape[0], 3, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
+    gen = torch.Generator(device=dev).manual_seed(2000 + rank)  # every rank draws its own slice of the global batch
+
+    def step():
+        idx = torch.randint(0, ro.shape[0], (T_RAYS,), device=dev, generator=gen)
+        opt.zero_grad(set_to_none=True)
+        (rgb, _, _, _), _, _ = Rm.render_rays(ro[idx], rd[idx], est, model, train=True, white_bkgd=True, device=dev)
+        loss = torch.nn.functional.mse_loss(rgb, gt[idx])
+        loss.backward()
+        shard.allreduce_grads(model.parameters())
+        opt.step()
+        sched.step()
+        return loss.detach()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    assert bool(torch.isfinite(loss))
+    if world > 1:
+        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        value = world * args.steps * T_RAYS / dt
+        achieved = FLOP_PER_RAY_TRAIN * value / world / 1e12  # per GPU, whole step (not one kernel)
+        line = {
+            "metric": "trained rays/sec (64+128 samples/ray, 8x256 MLP, fwd+bwd+Adam)", "value": value, "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+            "data": "synthetic",
+            "config": {"workload": "LLFF-style forward-facing scene, 8 views 378x504 (focal 407.6), NDC rays, near 0 / "
+                                   "far 1, 64 coarse + 128 importance samples, one 8x256 NeRF, MSE + Adam + "
+                                   "ExponentialDecay, flat-bucket gradient all-reduce",
+                       "rays_per_step": T_RAYS, "parallelism": f"dp{world} (ray-batch data parallel)"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_TFLOPS, "traffic": None, "kernel": "whole step",
+                         "flop_per_ray": FLOP_PER_RAY_TRAIN},
+            "loss": float(loss),
+        }
+        print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=("render", "train"), default="render")
     ap.add_argument("--precision", default=os.environ.get("FSN_BENCH_PREC", "fp16x3"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 3 if args.workload == "render" else 20
+    if args.warmup is None:
+        args.warmup = 1 if args.workload == "render" else 3
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,6 +231,12 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+
+    if args.workload == "train":
+        train_main(args, rank, world, dev, dist, backend)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     from fs_nerf_amd import ops
     from fs_nerf_amd.render import rendering as Rm

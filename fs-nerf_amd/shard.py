@@ -54,7 +54,12 @@ def allreduce_grads(params, average: bool = True) -> None:
     if not params or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return
     flat = torch.cat([p.grad.reshape(-1) for p in params])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if flat.is_cuda and dist.get_backend() == "gloo":  # CPU rehearsal backend: stage through host memory
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     if average:
         flat.div_(dist.get_world_size())
     off = 0
