@@ -202,6 +202,57 @@ def test_render_rays_train_step_matches_oracle():
     assert bool(torch.isfinite(out[0][0]).all())
 
 
+@pytest.mark.gpu
+def test_training_converges_on_rendered_targets():
+    """End to end: a student NeRF fitted by Adam to images rendered from a teacher NeRF (reference loop shape,
+    run-nerf.py:216-285: ray batch -> render_rays(train=True) -> mse -> backward -> step -> scheduler)."""
+    from fs_nerf_amd.core.models import NeRF
+    from fs_nerf_amd.core.scheduler import ExponentialDecay
+    from fs_nerf_amd.render import rendering as Rm
+    dev = torch.device("cuda:0")
+
+    def make(seed):
+        sd = O.init_nerf_state_dict(4, 128, [], 10, 4, seed=seed)
+        sd["sigma.weight"] *= 64.0
+        sd["sigma.bias"] += 3.0
+        m = NeRF(3, 3, 4, 128, (), pos_fn={"n_freqs": 10, "log_space": True}, dir_fn={"n_freqs": 4, "log_space": True})
+        m.load_state_dict(sd)
+        return m.to(dev)
+
+    teacher, student = make(21).eval(), make(22).train()
+    ro, rd = [], []
+    for phi in (0.0, 90.0, 180.0, 270.0):
+        o, d = O.get_rays(O.pose_from_spherical(4.0311289, 50.0, phi), (48, 48, 66.0))
+        ro.append(o.reshape(-1, 3))
+        rd.append(d.reshape(-1, 3))
+    ro, rd = torch.cat(ro).contiguous().to(dev), torch.cat(rd).contiguous().to(dev)
+    est_eval = Rm.StratifiedEstimator(2.0, 6.0, 64, 64)
+    with torch.no_grad():
+        gt = Rm.render_rays(ro, rd, est_eval, teacher, white_bkgd=True, device=dev)[0][0]
+    est = Rm.StratifiedEstimator(2.0, 6.0, 64, 64).train()
+    est.generator = torch.Generator(device=dev).manual_seed(0)
+    opt = torch.optim.Adam(student.parameters(), lr=1e-3)
+    sched = ExponentialDecay(opt, 300, 1e-3, r=0.1)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    losses = []
+    for it in range(300):
+        idx = torch.randint(0, ro.shape[0], (1024,), device=dev, generator=gen)
+        opt.zero_grad(set_to_none=True)
+        rgb = Rm.render_rays(ro[idx], rd[idx], est, student, train=True, white_bkgd=True, device=dev)[0][0]
+        loss = torch.nn.functional.mse_loss(rgb, gt[idx])
+        loss.backward()
+        opt.step()
+        sched.step()
+        losses.append(float(loss))
+    first, last = sum(losses[:10]) / 10, sum(losses[-10:]) / 10
+    assert all(np.isfinite(losses))
+    assert last < 0.25 * first, (first, last)
+    student.eval()
+    with torch.no_grad():  # the fused inference path sees the trained parameters (blob repacked)
+        full = Rm.render_rays(ro, rd, est_eval, student, white_bkgd=True, device=dev)[0][0]
+    assert float(torch.nn.functional.mse_loss(full, gt)) < 0.5 * first
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
