@@ -372,3 +372,52 @@ def composite_packed_bwd(sigmas, rgbs, t_starts, t_ends, ray_indices, n_rays, bk
         L.check(L.lib().fsn_composite_packed_bwd(_p(sig), _p(rgb), _p(t0), _p(t1), _p(ri), N, n_rays, _bk(bkgd), _p(dc),
                                                  _p(dop), _p(ds), _p(dr), _stream()), "fsn_composite_packed_bwd")
     return ds, dr
+
+
+# ------------------------------------------------------------------ occupancy-grid sampler
+def occgrid_march(rays_o: Tensor, rays_d: Tensor, aabb: Sequence[float], res: int, levels: int, bits: Tensor,
+                  near_plane: float, far_plane: float, step: float, u: Optional[Tensor], max_steps: int):
+    """Lattice march through the occupancy grid -> (ray_indices int64 [N], t_starts [N], t_ends [N], counts [R]).
+    Two launches around an exclusive scan of the per-ray counts; one host sync for N (as nerfacc's does)."""
+    o, d = _f32(rays_o, "rays_o").reshape(-1, 3), _f32(rays_d, "rays_d").reshape(-1, 3)
+    R = o.shape[0]
+    ab = (C.c_float * 6)(*[float(v) for v in aabb])
+    u_ = None if u is None else _f32(u, "u").reshape(-1)
+    if u_ is not None and u_.numel() != R:
+        raise ValueError("u must hold one value per ray")
+    counts = torch.zeros(R, device=o.device, dtype=torch.int64)
+    args = (_p(o), _p(d), R, ab, int(res), int(levels), _p(bits), float(near_plane), float(far_plane), float(step), _p(u_),
+            int(max_steps))
+    with torch.cuda.device(o.device):
+        L.check(L.lib().fsn_occgrid_march(*args, _p(counts), None, None, None, None, _stream()), "fsn_occgrid_march")
+        ends = torch.cumsum(counts, 0)
+        offsets = (ends - counts).contiguous()
+        N = int(ends[-1].item()) if R > 0 else 0
+        ri = torch.empty(N, device=o.device, dtype=torch.int64)
+        t0 = torch.empty(N, device=o.device, dtype=torch.float32)
+        t1 = torch.empty(N, device=o.device, dtype=torch.float32)
+        if N > 0:
+            L.check(L.lib().fsn_occgrid_march(*args, None, _p(offsets), _p(ri), _p(t0), _p(t1), _stream()), "fsn_occgrid_march")
+    return ri, t0, t1, counts
+
+
+def packed_visibility(sigmas: Tensor, t_starts: Tensor, t_ends: Tensor, ray_indices: Tensor, n_rays: int,
+                      early_stop_eps: float, alpha_thre: float) -> Tensor:
+    sig, t0, t1 = _f32(sigmas, "sigmas").reshape(-1), _f32(t_starts, "t_starts"), _f32(t_ends, "t_ends")
+    N = sig.numel()
+    keep = torch.zeros(N, device=sig.device, dtype=torch.uint8)
+    with torch.cuda.device(sig.device):
+        L.check(L.lib().fsn_packed_visibility(_p(sig), _p(t0), _p(t1), _p(ray_indices.contiguous()), N, int(n_rays),
+                                              float(early_stop_eps), float(alpha_thre), _p(keep), _stream()),
+                "fsn_packed_visibility")
+    return keep.bool()
+
+
+def occgrid_update(occs: Tensor, bits: Tensor, cells: Optional[Tensor], vals: Optional[Tensor], decay: float,
+                   threshold: Optional[Tensor]) -> None:
+    """occs[cells] = max(occs[cells]*decay, vals) (unique cells), then bits = occs > threshold (device scalar)."""
+    n = 0 if cells is None else cells.numel()
+    thr = None if threshold is None else _f32(threshold, "threshold").reshape(1)
+    with torch.cuda.device(occs.device):
+        L.check(L.lib().fsn_occgrid_update(_p(occs), occs.numel(), _p(cells), _p(None if vals is None else _f32(vals, "vals")),
+                                           n, float(decay), _p(thr), _p(bits), _stream()), "fsn_occgrid_update")

@@ -1,0 +1,102 @@
+"""Occupancy-grid estimator for the `estimator` slot of render_rays: the duck-typed interface
+the reference uses from nerfacc's OccGridEstimator — construction `OccGridEstimator(roi_aabb=, resolution=, levels=)`
+(src/run-nerf.py:96-98), `.sampling(rays_o, rays_d, sigma_fn=, render_step_size=, stratified=, near_plane=,
+far_plane=)` (src/render/rendering.py:66-74), `.update_every_n_steps(step=, occ_eval_fn=, occ_thre=)`
+(src/run-nerf.py:293-295), nn.Module modes / `.to()`.  nerfacc itself is not part of the reference; the sampling
+rule is this build's definition of that contract (see csrc/occgrid.hip), on HIP kernels."""
+import math
+from typing import Callable, Optional, Sequence
+
+import torch
+from torch import Tensor, nn
+
+from .. import ops
+
+
+class OccGridEstimator(nn.Module):
+    def __init__(self, roi_aabb, resolution: int = 128, levels: int = 1) -> None:
+        super().__init__()
+        aabb = [float(v) for v in (roi_aabb.tolist() if isinstance(roi_aabb, Tensor) else roi_aabb)]
+        if len(aabb) != 6:
+            raise ValueError("roi_aabb must hold 6 values {xmin, ymin, zmin, xmax, ymax, zmax}")
+        self.aabb, self.resolution, self.levels = aabb, int(resolution), int(levels)
+        n_cells = self.levels * self.resolution ** 3
+        if n_cells % 64:
+            raise ValueError("levels * resolution^3 must be a multiple of 64")
+        self.register_buffer("occs", torch.zeros(n_cells, dtype=torch.float32))
+        self.register_buffer("bits", torch.zeros(n_cells // 32, dtype=torch.int32))
+        self.generator: Optional[torch.Generator] = None
+
+    # -- helpers -------------------------------------------------------------------
+    @property
+    def binaries(self) -> Tensor:
+        """[levels, res, res, res] bool view of the bit field (nerfacc's attribute of the same name)."""
+        shifts = torch.arange(32, device=self.bits.device, dtype=torch.int32)
+        b = ((self.bits[:, None] >> shifts[None, :]) & 1).bool()
+        return b.reshape(self.levels, self.resolution, self.resolution, self.resolution)
+
+    def set_binaries(self, binaries: Tensor) -> None:
+        """Load an explicit occupancy ([levels, res, res, res] bool); occs become 1 / 0."""
+        flat = binaries.reshape(-1).to(self.occs.device)
+        self.occs.copy_(flat.float())
+        thr = torch.full((1,), 0.5, device=self.occs.device)
+        ops.occgrid_update(self.occs, self.bits, None, None, 1.0, thr)
+
+    def level_aabb(self, lvl: int):
+        c = [(self.aabb[a] + self.aabb[3 + a]) / 2.0 for a in range(3)]
+        h = [(self.aabb[3 + a] - self.aabb[a]) / 2.0 * 2 ** lvl for a in range(3)]
+        return [c[a] - h[a] for a in range(3)], [c[a] + h[a] for a in range(3)]
+
+    # -- reference surface ---------------------------------------------------------
+    @torch.no_grad()
+    def sampling(self, rays_o: Tensor, rays_d: Tensor, sigma_fn: Optional[Callable] = None,
+                 alpha_fn: Optional[Callable] = None, near_plane: float = 0.0, far_plane: float = 1e10,
+                 t_min: Optional[Tensor] = None, t_max: Optional[Tensor] = None, render_step_size: float = 1e-3,
+                 early_stop_eps: float = 1e-4, alpha_thre: float = 0.0, stratified: bool = False,
+                 cone_angle: float = 0.0, u: Optional[Tensor] = None):
+        """-> (ray_indices int64 [N], t_starts [N], t_ends [N]), packed and sorted by ray."""
+        if alpha_fn is not None or t_min is not None or t_max is not None or cone_angle != 0.0:
+            raise NotImplementedError("alpha_fn / t_min / t_max / cone_angle are not used by the reference")
+        R = rays_o.shape[0]
+        if u is None and stratified:
+            u = torch.rand(R, device=rays_o.device, generator=self.generator)
+        lo, hi = self.level_aabb(self.levels - 1)
+        diag = math.sqrt(sum((hi[a] - lo[a]) ** 2 for a in range(3)))
+        max_steps = int(min(16384, math.ceil(diag / render_step_size) + 2))
+        ri, t0, t1, _ = ops.occgrid_march(rays_o, rays_d, self.aabb, self.resolution, self.levels, self.bits, near_plane,
+                                          far_plane, render_step_size, u, max_steps)
+        if sigma_fn is not None and (early_stop_eps > 0.0 or alpha_thre > 0.0) and ri.numel() > 0:
+            sig = sigma_fn(t0, t1, ri)
+            keep = ops.packed_visibility(sig.reshape(-1), t0, t1, ri, R, early_stop_eps, alpha_thre)
+            ri, t0, t1 = ri[keep], t0[keep], t1[keep]
+        return ri, t0, t1
+
+    @torch.no_grad()
+    def update_every_n_steps(self, step: int, occ_eval_fn: Callable, occ_thre: float = 1e-2, ema_decay: float = 0.95,
+                             warmup_steps: int = 256, n: int = 16) -> None:
+        """Every n-th training step: re-evaluate cells (all of them during warm-up, else res^3/4 uniform + res^3/4
+        occupied ones) at a random point inside each, occs = max(occs*decay, occ), binaries = occs > min(mean, thre)."""
+        if not self.training or step % n != 0:
+            return
+        res, dev = self.resolution, self.occs.device
+        res3 = res ** 3
+        for lvl in range(self.levels):
+            if step < warmup_steps:
+                idx = torch.arange(res3, device=dev)
+            else:
+                k = res3 // 4
+                uni = torch.randint(res3, (k,), device=dev, generator=self.generator)
+                occd = torch.nonzero(self.binaries[lvl].reshape(-1)).reshape(-1)
+                if occd.numel() > k:
+                    occd = occd[torch.randint(occd.numel(), (k,), device=dev, generator=self.generator)]
+                idx = torch.unique(torch.cat([uni, occd]))
+            iz, iy, ix = idx % res, (idx // res) % res, idx // (res * res)
+            coords = torch.stack([ix, iy, iz], dim=-1).float()
+            x = (coords + torch.rand(idx.numel(), 3, device=dev, generator=self.generator)) / res
+            lo, hi = self.level_aabb(lvl)
+            lo_t, hi_t = torch.tensor(lo, device=dev), torch.tensor(hi, device=dev)
+            x = lo_t + x * (hi_t - lo_t)
+            occ = occ_eval_fn(x).reshape(-1).float()
+            ops.occgrid_update(self.occs, self.bits, (lvl * res3 + idx).contiguous(), occ, ema_decay, None)
+        thr = torch.clamp(self.occs.mean(), max=occ_thre).reshape(1)
+        ops.occgrid_update(self.occs, self.bits, None, None, 1.0, thr)

@@ -189,6 +189,13 @@ def render_frame(hwf: Tuple[int, int, float], near: float, far: float, pose: Ten
     rays_o, rays_d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
     if ndc:
         rays_o, rays_d = U.to_ndc(rays_o, rays_d, hwf, 1.0)
+    fine = model_fine if model_fine is not None else model
+    if isinstance(estimator, StratifiedEstimator) and isinstance(model, NeRF) and isinstance(fine, NeRF) and \
+            not (torch.is_grad_enabled() and fine.training):
+        # the fused kernel keeps nothing per sample in HBM, so `chunksize` (the reference's memory
+        # knob, 313 launches for an 800x800 frame at 2048) is not needed: ONE persistent launch per frame.  Rays are
+        # independent, so the image is the same as the chunked one.
+        chunksize = max(int(rays_o.shape[0]), 1)
     img, depth_map = [], []
     for co, cd in zip(U.get_chunks(rays_o, chunksize), U.get_chunks(rays_d, chunksize)):
         out = render_rays(co, cd, estimator, model, train=train, white_bkgd=white_bkgd,

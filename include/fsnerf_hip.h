@@ -200,6 +200,30 @@ int fsn_composite_packed_bwd(const float* sigmas, const float* rgbs, const float
                              const float* d_colors, const float* d_opacity, float* d_sigmas, float* d_rgbs,
                              fsn_stream_t stream);
 
+/* f2: occupancy-grid sampler for the `estimator` slot (nerfacc OccGridEstimator; call sites
+ * src/render/rendering.py:66-74, src/run-nerf.py:96-98, 288-295).  nerfacc is not part of the reference: the
+ * arithmetic is this build's definition of the contract, mirrored by oracle/fsnerf_oracle.py.
+ *   grid: `levels` nested boxes (level l = roi aabb scaled by 2^l about its centre), res^3 cells each, cell index
+ *   (ix*res + iy)*res + iz (+ l*res^3); `bits` = one bit per cell (word c>>5, bit c&31), `occs` fp32 per cell.
+ * fsn_occgrid_march: per ray the lattice t_k = near_r + k*step, near_r = near_plane + (u ? u[r]*step : 0); interval
+ *   [t_k, t_k+step) is a sample iff t_k lies in [max(t_enter, near_r), min(t_exit, far_plane)) of the outermost box
+ *   and the cell of its midpoint (finest level containing it) is occupied; at most max_steps lattice points per ray.
+ *   Two passes: offsets == NULL -> counts[R] (int64); else fill ray_indices / t_starts / t_ends at offsets[r]
+ *   (exclusive scan of the counts, by the caller).
+ * fsn_packed_visibility: keep[i] = (T_i >= early_stop_eps && alpha_i >= alpha_thre), T = exp(-exclusive sum of
+ *   sigma*dt) per ray, samples packed and sorted by ray.
+ * fsn_occgrid_update: occs[cells[i]] = max(occs[cells[i]]*decay, vals[i]) (cells must be unique), then, when
+ *   threshold_dev != NULL (device pointer to one float), bits = (occs > *threshold_dev). n_cells % 64 == 0. */
+int fsn_occgrid_march(const float* rays_o, const float* rays_d, int64_t R, const float* aabb_host, int res, int levels,
+                      const uint32_t* bits, float near_plane, float far_plane, float step, const float* u,
+                      int max_steps, int64_t* counts, const int64_t* offsets, int64_t* ray_indices, float* t_starts,
+                      float* t_ends, fsn_stream_t stream);
+int fsn_packed_visibility(const float* sigmas, const float* t_starts, const float* t_ends, const int64_t* ray_indices,
+                          int64_t N, int64_t R, float early_stop_eps, float alpha_thre, uint8_t* keep,
+                          fsn_stream_t stream);
+int fsn_occgrid_update(float* occs, int64_t n_cells, const int64_t* cells, const float* vals, int64_t n, float decay,
+                       const float* threshold_dev, uint32_t* bits, fsn_stream_t stream);
+
 /* f3: to8b(x) = (255 * clip(x, 0, 1)).astype(uint8)                    src/render/rendering.py:21 */
 int fsn_to8b(const float* x, int64_t n, uint8_t* out, fsn_stream_t stream);
 

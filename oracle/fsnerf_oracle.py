@@ -351,3 +351,81 @@ def render_rays_oracle(rays_o: Tensor, rays_d: Tensor, sd_coarse: Dict[str, Tens
         extras["weights_coarse"] = w_coarse
     ri, ts, te = edges_to_packed(edges)
     return (colors, opacity, depth, extras), ri, (ts + te) / 2.0
+
+
+# ------------------------------------------------------------------ occupancy-grid sampler
+# PARITY UNPINNED: nerfacc (OccGridEstimator) is not part of the reference and is not installed; these functions
+# restate THIS build's definition of the estimator contract (DESIGN.md "occupancy sampler"), operation for
+# operation in float32, for the kernels in csrc/occgrid.hip.  Call sites they serve: src/render/rendering.py:66-74.
+def occgrid_march(rays_o: Tensor, rays_d: Tensor, aabb: Sequence[float], res: int, levels: int, binaries: Tensor,
+                  near_plane: float, far_plane: float, step: float, u: Optional[Tensor] = None,
+                  max_steps: int = 16384) -> Tuple[Tensor, Tensor, Tensor]:
+    """-> (ray_indices int64 [N], t_starts [N], t_ends [N]); binaries bool [levels,res,res,res]."""
+    import numpy as np
+    f = np.float32
+    o_all, d_all = rays_o.numpy().astype(f), rays_d.numpy().astype(f)
+    amin, amax = np.array(aabb[:3], f), np.array(aabb[3:], f)
+    c, h = (amin + amax) / f(2), (amax - amin) / f(2)
+    bins = binaries.numpy().reshape(levels, -1)
+    step, near_plane, far_plane = f(step), f(near_plane), f(far_plane)
+    sc = f(1 << (levels - 1))
+    ri, ts_out, te_out = [], [], []
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        for r in range(o_all.shape[0]):
+            o, d = o_all[r], d_all[r]
+            tmin, tmax, miss = f(-np.inf), f(np.inf), False
+            for a in range(3):
+                hh = h[a] * sc
+                lo, hi = c[a] - hh, c[a] + hh
+                if d[a] == 0:
+                    miss = miss or o[a] < lo or o[a] > hi
+                else:
+                    ta, tb = (lo - o[a]) / d[a], (hi - o[a]) / d[a]
+                    tmin, tmax = max(tmin, min(ta, tb)), min(tmax, max(ta, tb))
+            near_r = near_plane + f(u[r]) * step if u is not None else near_plane
+            t_lo, t_hi = max(tmin, near_r), min(tmax, far_plane)
+            if miss or not (t_hi > t_lo):
+                continue
+            k0 = max(int(np.ceil((t_lo - near_r) / step)), 0)
+            k = np.arange(k0, k0 + max_steps, dtype=np.int64)
+            ts = near_r + k.astype(f) * step
+            te = ts + step
+            rng = (ts >= t_lo) & (ts < t_hi)
+            # the kernel stops at the first 64-block whose first lattice point is past the box; points beyond are
+            # out of range anyway
+            tm = (ts + te) / f(2)
+            p = o[None, :] + d[None, :] * tm[:, None]
+            keep = np.zeros(len(k), bool)
+            done = np.zeros(len(k), bool)
+            s = f(1)
+            for l in range(levels):
+                lo, hi = c - h * s, c + h * s
+                inside = np.all((p >= lo) & (p <= hi), axis=1) & ~done
+                q = np.floor((p - lo) / (hi - lo) * f(res)).astype(np.int64)
+                q = np.clip(q, 0, res - 1)
+                cell = (q[:, 0] * res + q[:, 1]) * res + q[:, 2]
+                keep |= inside & bins[l][cell]
+                done |= inside
+                s = s * f(2)
+            keep &= rng
+            n = int(keep.sum())
+            ri.append(np.full(n, r, np.int64))
+            ts_out.append(ts[keep])
+            te_out.append(te[keep])
+    cat = lambda xs, dt: torch.from_numpy(np.concatenate(xs) if xs else np.zeros(0, dt))
+    return cat(ri, np.int64), cat(ts_out, f), cat(te_out, f)
+
+
+def packed_visibility(sigmas: Tensor, t_starts: Tensor, t_ends: Tensor, ray_indices: Tensor, n_rays: int,
+                      early_stop_eps: float = 1e-4, alpha_thre: float = 0.0) -> Tensor:
+    """keep[i] = T_i >= eps and alpha_i >= alpha_thre with T = exp(-exclusive per-ray sum of sigma*dt) (float64)."""
+    sdt = (sigmas * (t_ends - t_starts)).double()
+    keep = torch.zeros(sdt.shape[0], dtype=torch.bool)
+    for r in range(n_rays):
+        m = ray_indices == r
+        if not bool(m.any()):
+            continue
+        s = sdt[m]
+        T = torch.exp(-(torch.cumsum(s, 0) - s))
+        keep[m] = (T >= early_stop_eps) & ((1.0 - torch.exp(-s)) >= alpha_thre)
+    return keep

@@ -1,0 +1,168 @@
+"""Occupancy-grid estimator: lattice march, visibility filter, grid update and the whole
+render_rays path with the estimator in the reference's slot.  PARITY UNPINNED against nerfacc (absent here): the
+checks are against oracle/fsnerf_oracle.py's restatement of this build's definition, plus properties."""
+import numpy as np
+import pytest
+import torch
+
+import fs_nerf_amd  # noqa: F401
+from oracle import fsnerf_oracle as O
+
+AABB = [-1.5, -1.5, -1.5, 1.5, 1.5, 1.5]
+
+
+def _sphere_binaries(res, levels, radius=0.9):
+    out = []
+    for l in range(levels):
+        half = 1.5 * 2 ** l
+        c = (torch.arange(res).float() + 0.5) / res * 2 * half - half
+        x, y, z = torch.meshgrid(c, c, c, indexing="ij")
+        out.append((x * x + y * y + z * z).sqrt() < radius * (1 + l))
+    return torch.stack(out)
+
+
+def _orbit_rays(n, seed):
+    o, d = O.get_rays(O.pose_from_spherical(4.0311289, 50.0, 20.0 * seed), (40, 40, 55.0))
+    o, d = o.reshape(-1, 3), d.reshape(-1, 3)
+    idx = torch.randperm(o.shape[0], generator=torch.Generator().manual_seed(seed))[:n]
+    return o[idx].contiguous(), d[idx].contiguous()
+
+
+def test_oracle_march_properties():
+    """CPU: samples lie on the lattice, inside the box, only in occupied cells, sorted by ray and by t."""
+    res, levels = 16, 2
+    bins = _sphere_binaries(res, levels)
+    o, d = _orbit_rays(50, 1)
+    u = torch.rand(50, generator=torch.Generator().manual_seed(0))
+    ri, t0, t1 = O.occgrid_march(o, d, AABB, res, levels, bins, 0.0, 1e10, 0.05, u)
+    assert ri.numel() > 100 and bool((ri[1:] >= ri[:-1]).all())
+    same = ri[1:] == ri[:-1]
+    assert bool((t0[1:][same] > t0[:-1][same]).all())
+    k = (t0 - u[ri] * 0.05) / 0.05
+    assert float((k - k.round()).abs().max()) < 1e-3
+    np.testing.assert_allclose((t1 - t0).numpy(), 0.05, rtol=1e-4)
+    p = o[ri] + d[ri] * ((t0 + t1) / 2)[:, None]
+    assert float(p.abs().max()) <= 3.0 + 1e-5                      # outermost box of 2 levels
+    # empty grid -> no samples; full grid -> every lattice interval starting inside the box
+    z = O.occgrid_march(o, d, AABB, res, levels, torch.zeros_like(bins), 0.0, 1e10, 0.05, None)
+    assert z[0].numel() == 0
+    f = O.occgrid_march(o, d, AABB, res, levels, torch.ones_like(bins), 0.0, 1e10, 0.05, None)
+    assert f[0].numel() > ri.numel()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("res,levels,step,strat", [(16, 1, 0.05, False), (32, 2, 0.02, True), (128, 1, 5e-3, True)])
+def test_march_matches_oracle(res, levels, step, strat):
+    from fs_nerf_amd.render.occgrid import OccGridEstimator
+    dev = torch.device("cuda:0")
+    est = OccGridEstimator(AABB, res, levels).to(dev)
+    bins = _sphere_binaries(res, levels)
+    est.set_binaries(bins)
+    assert torch.equal(est.binaries.cpu(), bins)
+    o, d = _orbit_rays(200, 3)
+    d[5] = torch.tensor([0.0, 0.0, -1.0])  # an axis-parallel ray (zero direction components)
+    o[5] = torch.tensor([0.2, -0.3, 4.0])
+    u = torch.rand(200, generator=torch.Generator().manual_seed(1)) if strat else None
+    ri, t0, t1 = est.sampling(o.to(dev), d.to(dev), render_step_size=step, stratified=strat,
+                              u=None if u is None else u.to(dev), near_plane=0.0, far_plane=1e10)
+    wri, wt0, wt1 = O.occgrid_march(o, d, AABB, res, levels, bins, 0.0, 1e10, step, u)
+    assert ri.numel() == wri.numel() and torch.equal(ri.cpu(), wri)
+    assert torch.equal(t0.cpu(), wt0) and torch.equal(t1.cpu(), wt1)  # same float32 lattice, bit for bit
+    # near / far planes clip the march
+    ri2, t02, _ = est.sampling(o.to(dev), d.to(dev), render_step_size=step, near_plane=3.5, far_plane=4.2)
+    assert ri2.numel() < ri.numel() and float(t02.min()) >= 3.5 and float(t02.max()) < 4.2
+
+
+@pytest.mark.gpu
+def test_visibility_filter_matches_oracle():
+    from fs_nerf_amd import ops
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(5)
+    R = 64
+    counts = torch.randint(0, 300, (R,), generator=gen)
+    counts[3] = 0
+    ri = torch.repeat_interleave(torch.arange(R), counts)
+    N = ri.numel()
+    t0 = torch.rand(N, generator=gen) * 4 + 2
+    t1 = t0 + 0.02
+    sig = torch.rand(N, generator=gen) * 40 - 2.0  # some negative densities, as the reference net emits
+    keep = ops.packed_visibility(sig.to(dev), t0.to(dev), t1.to(dev), ri.to(dev), R, 1e-2, 0.01)
+    want = O.packed_visibility(sig, t0, t1, ri, R, 1e-2, 0.01)
+    # T within 1e-5 relative of the threshold may land on either side in float32
+    sdt = (sig * (t1 - t0)).double()
+    Tex = torch.cat([torch.exp(-(torch.cumsum(sdt[ri == r], 0) - sdt[ri == r])) for r in range(R)])
+    sure = ((Tex / 1e-2 - 1).abs() > 1e-4) & (((1 - torch.exp(-sdt)) - 0.01).abs() > 1e-6)
+    assert torch.equal(keep.cpu()[sure], want[sure]) and int(want.sum()) > 0 and int((~want).sum()) > 0
+
+
+@pytest.mark.gpu
+def test_update_and_render_through_reference_call_shape():
+    """run-nerf.py's use of the estimator: update_every_n_steps with occ_eval_fn = model(x)*step, then render_rays
+    with the estimator in its slot (packed variable-length samples through model(x, d) and `rendering`), a training
+    step, and the all-background first batch of an empty grid."""
+    from fs_nerf_amd.core.models import NeRF
+    from fs_nerf_amd.render import rendering as Rm
+    from fs_nerf_amd.render.occgrid import OccGridEstimator
+    dev = torch.device("cuda:0")
+    sd = O.init_nerf_state_dict(4, 128, [], 10, 4, seed=4)
+    sd["sigma.weight"] *= 64.0
+    sd["sigma.bias"] += 3.0  # density > 0 in about a third of the volume
+    m = NeRF(3, 3, 4, 128, (), pos_fn={"n_freqs": 10, "log_space": True}, dir_fn={"n_freqs": 4, "log_space": True})
+    m.load_state_dict(sd)
+    m = m.to(dev).train()
+    est = OccGridEstimator(roi_aabb=torch.tensor(AABB), resolution=32, levels=1).to(dev).train()
+    est.generator = torch.Generator(device=dev).manual_seed(0)
+    o, d = _orbit_rays(256, 7)
+    step = 2e-2
+    # empty grid: zero samples, pure background, backward still legal through render_bkgd's slot (rendering.py:86)
+    (rgb, opacity, depth, extras), ri, tv = Rm.render_rays(o, d, est, m, train=True, white_bkgd=True,
+                                                           render_step_size=step, device=dev)
+    assert ri.numel() == 0 and bool((rgb == 1.0).all()) and float(depth.abs().max()) == 0.0
+
+    def occ_eval_fn(x):
+        return m(x) * step
+
+    est.generator.manual_seed(123)
+    est.update_every_n_steps(step=0, occ_eval_fn=occ_eval_fn, occ_thre=1e-2)
+    occ_frac = float(est.binaries.float().mean())
+    assert 0.0 < occ_frac < 1.0
+    # replay the warm-up update: every cell, one random point inside it, occs = max(0 * decay, sigma * step)
+    g2 = torch.Generator(device=dev).manual_seed(123)
+    idx = torch.arange(32 ** 3, device=dev)
+    coords = torch.stack([idx // 1024, (idx // 32) % 32, idx % 32], -1).float()
+    x_c = (coords + torch.rand(32 ** 3, 3, device=dev, generator=g2)) / 32 * 3.0 - 1.5
+    with torch.no_grad():
+        dens = m(x_c).reshape(-1) * step
+    assert torch.allclose(est.occs, dens.clamp(min=0.0), rtol=1e-5, atol=1e-6)
+    thr = min(float(est.occs.mean()), 1e-2)
+    assert torch.equal(est.binaries.reshape(-1), est.occs > thr)
+    est.update_every_n_steps(step=1, occ_eval_fn=occ_eval_fn)  # not a multiple of n: no-op
+    before = est.occs.clone()
+    est.update_every_n_steps(step=512, occ_eval_fn=occ_eval_fn)  # past warm-up: subset + EMA decay
+    assert not torch.equal(before, est.occs)
+    # render + one optimisation step through the packed path
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    (rgb, opacity, depth, extras), ri, tv = Rm.render_rays(o, d, est, m, train=True, white_bkgd=True,
+                                                           render_step_size=step, device=dev)
+    assert ri.numel() > 0 and rgb.requires_grad and extras["weights"].shape == ri.shape
+    n_per_ray = torch.bincount(ri, minlength=256)
+    assert int(n_per_ray.max()) > int(n_per_ray.min())  # variable-length
+    loss = torch.nn.functional.mse_loss(rgb, torch.rand(256, 3, device=dev))
+    loss.backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+    opt.step()
+    # oracle on the same packed samples
+    m.eval()
+    est.eval()
+    with torch.no_grad():
+        (rgb, opacity, depth, extras), ri, tv = Rm.render_rays(o, d, est, m, white_bkgd=True, render_step_size=step, device=dev)
+    sd2 = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    t0, t1 = (tv - step / 2).cpu(), (tv + step / 2).cpu()
+    ric = ri.cpu()
+
+    def fn(a, b, c):
+        out = O.nerf_forward(sd2, (o[c] + d[c] * ((a + b) / 2)[:, None]), d[c], n_layers=4, skip=[], n_freqs=10, n_freqs_dir=4)
+        return out[:, :3], out[:, 3]
+
+    wc, wo, wd, _ = O.rendering_packed(t0, t1, ric, 256, fn, torch.ones(3))
+    assert float((rgb.cpu() - wc).abs().max()) < 2e-4 and float((opacity.cpu() - wo).abs().max()) < 2e-4
