@@ -351,6 +351,8 @@ def nerf_train_bwd(desc: L.MlpDesc, prec: int, weights: Sequence[Tensor], work: 
     ws_ = [_f32(w.detach(), "weight") for w in weights]
     d_out = _f32(d_out, "d_out").reshape(-1, 4)
     n = d_out.shape[0]
+    if n == 0:  # e.g. the all-background first batch of an empty occupancy grid (run-nerf.py:243 precedes :293)
+        return [torch.zeros_like(w) for w in ws_], [torch.zeros(w.shape[0], device=w.device) for w in ws_]
     dW = [torch.empty_like(w) for w in ws_]
     db = [torch.empty(w.shape[0], device=w.device, dtype=torch.float32) for w in ws_]
     scale = grad_scale_for(d_out) if prec in (L.FSN_PREC_FP16X3, L.FSN_PREC_FP16) else None

@@ -83,6 +83,29 @@ def test_nerf_gradients_vs_autograd(n_layers, d_hidden, skip, nf, nfd, cscale, t
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 5, 129])
+def test_nerf_gradients_tiny_batches(n):
+    """Fewer samples than one 128-sample tile / one more than a tile: padded columns must contribute nothing."""
+    from fs_nerf_amd.core.models import NeRF
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    m = NeRF(3, 3, 8, 256, (4,), pos_fn={"n_freqs": 10, "log_space": True}, dir_fn={"n_freqs": 4, "log_space": True})
+    m = m.to(dev).train()
+    x = torch.rand(n, 3, device=dev) * 2 - 1
+    d = torch.nn.functional.normalize(torch.randn(n, 3, device=dev), dim=-1)
+    c = torch.randn(n, 4, device=dev)
+    grads = {}
+    for tp in ("fp32", None):
+        m.train_precision = tp
+        m.zero_grad(set_to_none=True)
+        (m(x, d) * c).sum().backward()
+        grads[tp] = {k: p.grad.clone() for k, p in m.named_parameters()}
+    for k in grads[None]:
+        assert bool(torch.isfinite(grads[None][k]).all())
+        assert _rel(grads[None][k], grads["fp32"][k]) < 2e-3, (k, _rel(grads[None][k], grads["fp32"][k]))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mask", [False, True])
 def test_nerf_gradients_mfma_vs_plain_many_tiles(mask):
     """40,001 samples = 313 tiles (more than the wgrad's split count, last tile ragged): the MFMA path against the
