@@ -489,23 +489,27 @@ __device__ __forceinline__ void mlp_tile(WStream& st, const NetDev& net, const S
   const float* misc = net.aux + (L + 5) * D;
   Frag A[NA], B[NA];
   Frag none[1];
-  Frag pe[kKsPos];
   Heads heads{0.f, {0.f, 0.f, 0.f}};
   {
+    Frag pe[kKsPos];
     float px, py, pz;
     src.pos(px, py, pz);
     encode<kKsPos, F16, X3, SV::kSave>(px, py, pz, net.n_freqs_pos, misc + 4, net.pos_mask, g, pe, sv.enc_pos(g));
-  }
-  {
     typename SV::Hook hk = sv.hidden(0);
     gemm_layer<PREC, NT, 0, kKsPos, EPI_RELU_CVT>(st, net, 0, none, pe, A, heads, ring, g, hk);
   }
+  // A wide (skip) layer re-encodes the position instead of keeping the 16 registers of `pe` alive across the layers
+  // in between (same function of the same inputs: identical values; fused kernel: 360 -> 256 B of scratch, +1.5 %).
 #define FSN_HIDDEN(EPI, IN, OUT, LIDX)                                                        \
   do {                                                                                        \
     typename SV::Hook hk = sv.hidden(LIDX);                                                   \
-    if ((net.skip_mask >> ((LIDX)-1)) & 1u)                                                   \
-      gemm_layer<PREC, NT, NA, kKsPos, EPI>(st, net, (LIDX)*D, IN, pe, OUT, heads, ring, g, hk);  \
-    else                                                                                      \
+    if ((net.skip_mask >> ((LIDX)-1)) & 1u) {                                                 \
+      Frag pe2[kKsPos];                                                                       \
+      float qx, qy, qz;                                                                       \
+      src.pos(qx, qy, qz);                                                                    \
+      encode<kKsPos, F16, X3, false>(qx, qy, qz, net.n_freqs_pos, misc + 4, net.pos_mask, g, pe2); \
+      gemm_layer<PREC, NT, NA, kKsPos, EPI>(st, net, (LIDX)*D, IN, pe2, OUT, heads, ring, g, hk); \
+    } else                                                                                    \
       gemm_layer<PREC, NT, NA, 0, EPI>(st, net, (LIDX)*D, IN, none, OUT, heads, ring, g, hk);     \
   } while (0)
   for (int l = 1; l <= L - 2; l += 2) {
