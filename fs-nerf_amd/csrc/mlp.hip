@@ -1,6 +1,9 @@
 // mlp.hip — weight packing (host + device) and the standalone NeRF.forward kernel.
 // reference: src/core/models.py:53-143 (NeRF), state_dict layout SURVEY.md 8a (a5).
 #include "common.hpp"
+// x3 modes: pinned one-unit-ahead LDS prefetch of the A operands (mlp_dev.hpp).  +6 % on these kernels; the fused
+// render kernel keeps the compiler's own read placement (with its larger live state the pinned form spills more).
+#define FSN_X3_PF1
 #include "mlp_dev.hpp"
 #include "mlp_layout.hpp"
 

@@ -343,6 +343,11 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
   constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
   static_assert(kLead == 2, "the A-operand prefetch distance (one k-step = two units) equals the phase lead");
   constexpr bool PREFETCH = !X3;
+#ifdef FSN_X3_PF1
+  constexpr bool kX3Pf1 = X3;
+#else
+  constexpr bool kX3Pf1 = false;
+#endif
   constexpr int UPP = X3 ? 8 : 16;
   constexpr int UB = X3 ? 2048 : 1024;
   constexpr int KS = KS_ACT + KS_ENC;
@@ -383,6 +388,25 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
         __builtin_amdgcn_sched_group_barrier(0x100, X3 ? 4 : 2, 0);  // DS reads
         __builtin_amdgcn_sched_group_barrier(0x008, X3 ? 6 : 2, 0);  // MFMAs
         __builtin_amdgcn_sched_barrier(0);
+      } else if constexpr (kX3Pf1) {
+        // x3 modes: A operands of the NEXT unit are read in front of this unit's three MFMAs (8 registers in flight)
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+          const int u = (tp * KS + ks) * 2 + sub;
+          if (((u + kLead) % UPP == 0 && u + kLead <= TOTAL) || (u + kLead == TOTAL && TOTAL % UPP != 0)) st.open_next();
+          if (u % UPP == 0) st.enter_phase();
+          const int v = u + 1;
+          const char* src = (v < TOTAL) ? ((v / UPP == u / UPP) ? st.c_base : st.n_base) + (v % UPP) * UB
+                                        : st.n_base + (v - TOTAL) * UB;
+          AFrag nxt;
+          load_afrag<PREC>(src, nxt);
+          if (sub == 0) unit_mfma_r<PREC>(ring.cur[0], b, acc0);
+          else unit_mfma_r<PREC>(ring.cur[0], b, acc1);
+          ring.cur[0] = nxt;
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS reads
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);  // MFMAs
+          __builtin_amdgcn_sched_barrier(0);
+        }
       } else {
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -458,10 +482,17 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
 template <int PREC>
 __device__ __forceinline__ void prime_ring(const WStream& st, ARing& ring) {
   constexpr int UB = (PREC & 1) == 0 ? 2048 : 1024;
+#ifdef FSN_X3_PF1
+  if ((PREC & 1) == 0) {
+    load_afrag<PREC>(st.n_base, ring.cur[0]);
+    return;
+  }
+#else
   if ((PREC & 1) == 0) return;  // the x3 modes read their operands in place
+#endif
   load_afrag<PREC>(st.n_base, ring.cur[0]);
   load_afrag<PREC>(st.n_base + UB, ring.cur[1]);
-  ring.cur[0].lo = ring.cur[1].lo = ring.cur[0].hi;
+  if ((PREC & 1) != 0) ring.cur[0].lo = ring.cur[1].lo = ring.cur[0].hi;  // single pass: no low parts
 }
 
 // ---------------------------------------------------------------- whole network, one tile

@@ -21,6 +21,9 @@
 // gradients sit in fp16's range; bf16 modes need none.
 //
 // reference: src/core/models.py:111-143 (forward), src/run-nerf.py:243-285 (loss.backward()).
+// x3 modes: pinned one-unit-ahead LDS prefetch of the A operands (mlp_dev.hpp).  +6 % on these kernels; the fused
+// render kernel keeps the compiler's own read placement (with its larger live state the pinned form spills more).
+#define FSN_X3_PF1
 #include "mlp_dev.hpp"
 #include "mlp_layout.hpp"
 #include "train_internal.hpp"
