@@ -27,6 +27,8 @@ struct RenderLds {
   // The launch arguments live in LDS, not in SGPRs: they are read where they are used (mostly between the
   // MLP passes) instead of being held - and spilled - across the register-starved MFMA passes.
   fsn_render_args args;
+  int32_t Gc, nsubC, nsubF;  // RenderKArgs::G / nsubC / nsubF / step
+  float step;
   float rays[kMaxG * 6];
   float edgesC[kMaxGroupSamples + kMaxG];
   float sigC[kMaxGroupSamples];
@@ -56,6 +58,13 @@ struct RaySrc {
   __device__ __forceinline__ void dir(float& x, float& y, float& z) const { x = ray[3]; y = ray[4]; z = ray[5]; }
 };
 
+// per-launch parameters of k_render_fused, read from LDS at the point of use
+#define GRP_S (a.S)
+#define GRP_NI (a.n_imp)
+#define GRP_SO (a.S + a.n_imp)
+#define GRP_HIER (a.n_imp > 0)
+#define GRP_G (S_.Gc)
+#define GRP_R (a.R)
 template <int NT, int PREC>
 __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
   __shared__ __attribute__((aligned(1024))) char smem[kRenderLdsBytes];
@@ -65,71 +74,71 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
   if (threadIdx.x == 0) S_.args = k.a;
   __syncthreads();
   const fsn_render_args& a = S_.args;
-  const int S = a.S, NI = a.n_imp, So = S + NI, G = k.G;
-  const bool hier = NI > 0;
+  // Loop parameters are read from LDS where they are used (GRP_* below) rather than cached in registers for the
+  // whole kernel: 73 fewer spilled SGPRs and 24 fewer spilled VGPRs around the MFMA passes, +2 % (A/B on MI355X).
+  if (threadIdx.x == 0) { S_.Gc = k.G; S_.nsubC = k.nsubC; S_.nsubF = k.nsubF; S_.step = k.step; }
+  __syncthreads();
   NetDev netC, netF;
   load_net(k.netF, a.pos_mask, a.dir_mask, auxF, netF);
-  if (hier) load_net(k.netC, a.pos_mask, a.dir_mask, auxC, netC);
+  if (GRP_HIER) load_net(k.netC, a.pos_mask, a.dir_mask, auxC, netC);
   else netC = netF;
   __syncthreads();
   WStream st;
-  st.init(smem, k.netC.blob + k.netC.stream_off, hier ? (uint32_t)k.netC.nph_density : 0u, (uint32_t)k.nsubC,
+  st.init(smem, k.netC.blob + k.netC.stream_off, GRP_HIER ? (uint32_t)k.netC.nph_density : 0u, (uint32_t)k.nsubC,
           k.netF.blob + k.netF.stream_off, (uint32_t)k.netF.nph_full, (uint32_t)k.nsubF);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   ARing ring;
   prime_ring<PREC>(st, ring);
-  const int64_t R = a.R;
-  const int64_t ngroups = (R + G - 1) / G;
-  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const int64_t r0 = grp * G;
+  for (int64_t grp = blockIdx.x; grp < (GRP_R + GRP_G - 1) / GRP_G; grp += gridDim.x) {
+    const int64_t r0 = grp * GRP_G;
     // ---- rays and coarse interval edges into LDS
-    if (tid < G * 6) {
+    if (tid < GRP_G * 6) {
       const int g = tid / 6, c = tid - 6 * g;
-      const int64_t ray = min(r0 + g, R - 1);
+      const int64_t ray = min(r0 + g, GRP_R - 1);
       S_.rays[tid] = c < 3 ? a.rays_o[3 * ray + c] : a.rays_d[3 * ray + c - 3];
     }
-    for (int e = tid; e < G * (S + 1); e += kThreads) {
-      const int g = e / (S + 1), i = e - g * (S + 1);
-      const int64_t ray = min(r0 + g, R - 1);
-      const float* ur = a.u_mode == 1 ? a.u + ray : (a.u_mode == 2 ? a.u + ray * (S + 1) : nullptr);
-      S_.edgesC[e] = stratified_edge(a.near, k.step, S, i, a.u_mode, ur);
+    for (int e = tid; e < GRP_G * (GRP_S + 1); e += kThreads) {
+      const int g = e / (GRP_S + 1), i = e - g * (GRP_S + 1);
+      const int64_t ray = min(r0 + g, GRP_R - 1);
+      const float* ur = a.u_mode == 1 ? a.u + ray : (a.u_mode == 2 ? a.u + ray * (GRP_S + 1) : nullptr);
+      S_.edgesC[e] = stratified_edge(a.near, S_.step, GRP_S, i, a.u_mode, ur);
     }
     lds_barrier();
-    if (hier) {
+    if (GRP_HIER) {
       // ---- density pass of the coarse net (sigma_fn, rendering.py:58-64)
-      for (int sub = 0; sub < k.nsubC; ++sub) {
+      for (int sub = 0; sub < S_.nsubC; ++sub) {
         const int idx = sub * 128 + wave * 16 + (lane & 15);
-        const int idc = min(idx, G * S - 1);
-        const int g = idc / S, i = idc - g * S;
-        const RaySrc src{S_.rays + 6 * g, S_.edgesC + g * (S + 1) + i};
+        const int idc = min(idx, GRP_G * GRP_S - 1);
+        const int g = idc / GRP_S, i = idc - g * GRP_S;
+        const RaySrc src{S_.rays + 6 * g, S_.edgesC + g * (GRP_S + 1) + i};
         float sigma, rgb[3];
         mlp_tile<NT, PREC, false>(st, netC, src, ring, sigma, rgb);
-        if (lane < 16 && idx < G * S) S_.sigC[idx] = sigma;
+        if (lane < 16 && idx < GRP_G * GRP_S) S_.sigC[idx] = sigma;
       }
       lds_barrier();
       // ---- per-ray weights, inverse-CDF resampling, sorted union (one wave per ray)
-      for (int g = wave; g < G; g += kWaves) {
-        const int64_t ray = min(r0 + g, R - 1);
-        float* wc = S_.wC + g * S;
-        weights_ray(S_.sigC + g * S, S_.edgesC + g * (S + 1), S, wc);
+      for (int g = wave; g < GRP_G; g += kWaves) {
+        const int64_t ray = min(r0 + g, GRP_R - 1);
+        float* wc = S_.wC + g * GRP_S;
+        weights_ray(S_.sigC + g * GRP_S, S_.edgesC + g * (GRP_S + 1), GRP_S, wc);
         __builtin_amdgcn_wave_barrier();
-        if (a.weights_coarse && r0 + g < R)
-          for (int i = lane; i < S; i += 64) a.weights_coarse[ray * S + i] = wc[i];
-        sample_pdf_merge_ray(S_.edgesC + g * (S + 1), wc, S, NI, a.u_fine ? a.u_fine + ray * NI : nullptr,
-                             S_.cdf[g], S_.vals[g], S_.edgesF + g * (So + 1));
+        if (a.weights_coarse && r0 + g < GRP_R)
+          for (int i = lane; i < GRP_S; i += 64) a.weights_coarse[ray * GRP_S + i] = wc[i];
+        sample_pdf_merge_ray(S_.edgesC + g * (GRP_S + 1), wc, GRP_S, GRP_NI, a.u_fine ? a.u_fine + ray * GRP_NI : nullptr,
+                             S_.cdf[g], S_.vals[g], S_.edgesF + g * (GRP_SO + 1));
       }
       lds_barrier();
     }
-    const float* edges = hier ? S_.edgesF : S_.edgesC;
+    const float* edges = GRP_HIER ? S_.edgesF : S_.edgesC;
     // ---- full pass of the fine net (rgb_sigma_fn, rendering.py:76-84)
-    for (int sub = 0; sub < k.nsubF; ++sub) {
+    for (int sub = 0; sub < S_.nsubF; ++sub) {
       const int idx = sub * 128 + wave * 16 + (lane & 15);
-      const int idc = min(idx, G * So - 1);
-      const int g = idc / So, i = idc - g * So;
-      const RaySrc src{S_.rays + 6 * g, edges + g * (So + 1) + i};
+      const int idc = min(idx, GRP_G * GRP_SO - 1);
+      const int g = idc / GRP_SO, i = idc - g * GRP_SO;
+      const RaySrc src{S_.rays + 6 * g, edges + g * (GRP_SO + 1) + i};
       float sigma, rgb[3];
       mlp_tile<NT, PREC, true>(st, netF, src, ring, sigma, rgb);
-      if (lane < 16 && idx < G * So) {
+      if (lane < 16 && idx < GRP_G * GRP_SO) {
         S_.sigF[idx] = sigma;
         S_.rgbF[3 * idx + 0] = rgb[0];
         S_.rgbF[3 * idx + 1] = rgb[1];
@@ -138,25 +147,32 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
     }
     lds_barrier();
     // ---- volume integration (nerfacc rendering arithmetic, rendering.py:89-96), one wave per ray
-    for (int g = wave; g < G; g += kWaves) {
-      if (r0 + g >= R) continue;
+    for (int g = wave; g < GRP_G; g += kWaves) {
+      if (r0 + g >= GRP_R) continue;
       const int64_t ray = r0 + g;
-      const float* eg = edges + g * (So + 1);
+      const float* eg = edges + g * (GRP_SO + 1);
       CompositeOut o{a.colors + 3 * ray, a.opacity + ray, a.depth + ray,
-                     a.weights ? a.weights + ray * So : nullptr, a.alphas ? a.alphas + ray * So : nullptr,
-                     a.trans ? a.trans + ray * So : nullptr};
-      composite_ray(S_.sigF + g * So, S_.rgbF + 3 * g * So, eg, eg + 1, So, true, a.bkgd[0], a.bkgd[1], a.bkgd[2], o);
+                     a.weights ? a.weights + ray * GRP_SO : nullptr, a.alphas ? a.alphas + ray * GRP_SO : nullptr,
+                     a.trans ? a.trans + ray * GRP_SO : nullptr};
+      composite_ray(S_.sigF + g * GRP_SO, S_.rgbF + 3 * g * GRP_SO, eg, eg + 1, GRP_SO, true, a.bkgd[0], a.bkgd[1], a.bkgd[2], o);
       if (a.sigmas)
-        for (int i = lane; i < So; i += 64) a.sigmas[ray * So + i] = S_.sigF[g * So + i];
+        for (int i = lane; i < GRP_SO; i += 64) a.sigmas[ray * GRP_SO + i] = S_.sigF[g * GRP_SO + i];
       if (a.rgbs)
-        for (int i = lane; i < 3 * So; i += 64) a.rgbs[ray * So * 3 + i] = S_.rgbF[3 * g * So + i];
+        for (int i = lane; i < 3 * GRP_SO; i += 64) a.rgbs[ray * GRP_SO * 3 + i] = S_.rgbF[3 * g * GRP_SO + i];
       if (a.edges_out)
-        for (int i = lane; i <= So; i += 64) a.edges_out[ray * (So + 1) + i] = eg[i];
+        for (int i = lane; i <= GRP_SO; i += 64) a.edges_out[ray * (GRP_SO + 1) + i] = eg[i];
     }
     lds_barrier();
   }
   st.drain();
 }
+
+#undef GRP_S
+#undef GRP_NI
+#undef GRP_SO
+#undef GRP_HIER
+#undef GRP_G
+#undef GRP_R
 
 template <int NT, int PREC>
 static int launch_render(const RenderKArgs& k, int cus, hipStream_t s) {
