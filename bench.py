@@ -139,7 +139,7 @@ def train_main(args, rank, world, dev, dist, backend):
     model.to(dev).train()
     est = Rm.StratifiedEstimator(0.0, 1.0, S, NI).train()  # NDC: near 0, far 1 (llff.py:51-53)
     est.generator = torch.Generator(device=dev).manual_seed(1000 + rank)
-    opt = torch.optim.Adam(model.parameters(), lr=5e-4)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4, fused=os.environ.get("FSN_FUSED_ADAM", "1") == "1")
     sched = ExponentialDecay(opt, 10000, 5e-4, r=0.1)
     ro, rd = [], []
     for pose in train_poses():  # dataset ray precompute on the device (llff.py:59-90)
