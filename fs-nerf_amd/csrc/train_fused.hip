@@ -106,6 +106,13 @@ static int make_fused_layout(const fsn_mlp_desc& d, int prec, int64_t n, FusedLa
   return FSN_OK;
 }
 
+// saved activations / gradients are written once and read by a later kernel: streaming stores
+#ifdef FSN_NO_NT
+#define FSN_STREAM_STORE(v, p) (*(p) = (v))
+#else
+#define FSN_STREAM_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#endif
+
 // ------------------------------------------------------------------ forward with saved activations
 struct FwdSaver {
   static constexpr bool kSave = true;
@@ -120,7 +127,7 @@ struct FwdSaver {
       uint32_t b = 0;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        p[(32 * tp + 16 * (j >> 2) + (j & 3)) * kTC] = v[j];
+        FSN_STREAM_STORE(v[j], p + (32 * tp + 16 * (j >> 2) + (j & 3)) * kTC);
         b |= (v[j] > 0.f ? 1u : 0u) << j;
       }
       if (mk) mk[tp] = (uint8_t)b;  // byte stores: accumulating the 64-bit word in registers tips the x3 modes into scratch
@@ -251,7 +258,7 @@ struct BwdStoreHook {
   __device__ __forceinline__ void pre(int) {}
   __device__ __forceinline__ void post(int tp, float (&v)[8]) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) d[(32 * tp + 16 * (j >> 2) + (j & 3)) * kTC] = v[j];
+    for (int j = 0; j < 8; ++j) FSN_STREAM_STORE(v[j], d + (32 * tp + 16 * (j >> 2) + (j & 3)) * kTC);
   }
 };
 
@@ -277,7 +284,7 @@ struct BwdMaskHook {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       v[j] = ((bits >> j) & 1u) ? v[j] : 0.f;
-      d[(32 * tp + 16 * (j >> 2) + (j & 3)) * kTC] = v[j];
+      FSN_STREAM_STORE(v[j], d + (32 * tp + 16 * (j >> 2) + (j & 3)) * kTC);
     }
   }
 };
@@ -406,6 +413,10 @@ struct WgArgs {
   int32_t nsplit;
 };
 
+// wgrad operand loads stay ordinary loads: the two column-group waves that share an A row block find the second
+// read in L2 (nontemporal loads cost 35 % here), while the savers' streaming STORES gain 15 %.
+#define FSN_STREAM_LOAD(p) (*reinterpret_cast<const f32x4*>(p))
+
 template <bool F16>
 __device__ __forceinline__ f32x16 mfma32(const s16x8& a, const s16x8& b, const f32x16& c) {
   if (F16)
@@ -456,8 +467,8 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgArgs a) {
       const int R = 16 * ((it * kThreads + tid) >> 6) + (tid & 15);
       if (R < b_rows) {
         const float* p = jb.B + (t * b_rows + R) * kTC + 32 * c + 8 * sg;
-        braw[it][0] = *reinterpret_cast<const f32x4*>(p);
-        braw[it][1] = *reinterpret_cast<const f32x4*>(p + 4);
+        braw[it][0] = FSN_STREAM_LOAD(p);
+        braw[it][1] = FSN_STREAM_LOAD(p + 4);
       }
     }
 #pragma unroll
@@ -465,8 +476,8 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgArgs a) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const float* p = jb.A + (t * A_ROWS + 64 * rg + 32 * ti + m) * kTC + 32 * c + 16 * ks + 8 * kg;
-        araw[ti][ks][0] = *reinterpret_cast<const f32x4*>(p);
-        araw[ti][ks][1] = *reinterpret_cast<const f32x4*>(p + 4);
+        araw[ti][ks][0] = FSN_STREAM_LOAD(p);
+        araw[ti][ks][1] = FSN_STREAM_LOAD(p + 4);
       }
   };
   auto stage_b = [&](int buf) {
