@@ -20,6 +20,8 @@ Pinning status ("Oracle"):
     hierarchical 64+128 sampling, frequency mask); the reference has no such
     code.  PARITY UNPINNED; with mask == 1 and one network they reduce to the
     reference formulas.
+  * occgrid_march, packed_visibility (end of file) restate this build's definition of the
+    estimator contract the reference fills with nerfacc's OccGridEstimator.  PARITY UNPINNED.
 
 All functions take / return torch CPU tensors; `dtype` follows the inputs so the
 same code runs in float32 (parity oracle, CPU baseline) and float64 (truth for
