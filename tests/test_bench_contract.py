@@ -1,0 +1,44 @@
+"""bench.py prints ONE JSON line with the driver's contract keys plus `roofline` and `cpu_baseline`."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _run(*args):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                         timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_render_line_contract():
+    j = _run("--steps", "1", "--warmup", "1")
+    assert KEYS <= set(j) and "cpu_baseline" in j
+    assert j["n_gpus"] == 1 and j["steps"] == 1 and j["warmup"] == 1 and j["higher_is_better"] is True
+    assert j["scaling"] == "weak" and j["vs_baseline"] is None and j["data"] == "synthetic" and j["unit"] == "rays/s"
+    assert "800x800" in j["config"]["workload"] and "model" not in j["config"]
+    r = j["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.05 < r["frac"] < 0.34
+    # whole-job rate and the kernel-only rate describe the same launches
+    assert abs(j["value"] * r["flop_per_ray"] / 1e12 - r["achieved"]) < 0.1 * r["achieved"]
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "rays/s" and c["cores"] >= 1 and 1.0 < c["value"] < j["value"] / 100
+
+
+@pytest.mark.gpu
+def test_train_line_contract():
+    j = _run("--workload", "train", "--steps", "3", "--warmup", "1")
+    assert KEYS <= set(j) and j["steps"] == 3 and "trained rays/sec" in j["metric"]
+    assert j["config"]["rays_per_step"] == 4096 and j["config"]["parallelism"].startswith("dp1")
+    assert 0.0 < j["loss"] < 1.0 and j["value"] > 1e4
