@@ -475,7 +475,9 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgArgs a) {
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const float* p = jb.A + (t * A_ROWS + 64 * rg + 32 * ti + m) * kTC + 32 * c + 16 * ks + 8 * kg;
+        // k order inside the 32-sample chunk: lane group kg takes samples [16 kg, 16 kg + 16) (8 per k-step), so its
+        // four loads of a row are 64 contiguous bytes; the B staging below uses the same order
+        const float* p = jb.A + (t * A_ROWS + 64 * rg + 32 * ti + m) * kTC + 32 * c + 16 * kg + 8 * ks;
         araw[ti][ks][0] = FSN_STREAM_LOAD(p);
         araw[ti][ks][1] = FSN_STREAM_LOAD(p + 4);
       }
@@ -490,7 +492,7 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgArgs a) {
         for (int j = 0; j < 4; ++j) { v[j] = braw[it][0][j]; v[4 + j] = braw[it][1][j]; }
         Frag f;
         split_store<F16, X3>(v, f);
-        const int addr = ((((R >> 5) * 2 + (sg >> 1)) * 64) + (sg & 1) * 32 + (R & 31)) * 16;
+        const int addr = ((((R >> 5) * 2 + (sg & 1)) * 64) + (sg >> 1) * 32 + (R & 31)) * 16;  // sg = 2 kg + ks
         *reinterpret_cast<s16x8*>(&lds[buf][0][addr]) = f.hi;
         if (X3) *reinterpret_cast<s16x8*>(&lds[buf][1][addr]) = f.lo;
       }
