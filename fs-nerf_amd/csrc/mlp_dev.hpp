@@ -305,6 +305,19 @@ __device__ __forceinline__ void unit_mfma(const char* ubase, const Frag& b, f32x
   }
   return;
 #endif
+#ifdef FSN_ABL_LDSDUMMY  // timing experiment: the LDS reads are issued but nothing depends on them
+  {
+    const s16x8 dh = *reinterpret_cast<const s16x8*>(ubase);
+    const s16x8 dl = *reinterpret_cast<const s16x8*>(ubase + 1024);
+    acc = mfma16<F16>(b.lo, b.hi, acc);
+    if (X3) {
+      acc = mfma16<F16>(b.hi, b.hi, acc);
+      acc = mfma16<F16>(b.lo, b.lo, acc);
+    }
+    asm volatile("" ::"v"(dh), "v"(dl));
+    return;
+  }
+#endif
   const s16x8 ah = *reinterpret_cast<const s16x8*>(ubase);
   acc = mfma16<F16>(ah, b.hi, acc);
   if (X3) {
