@@ -141,13 +141,7 @@ def train_main(args, rank, world, dev, dist, backend):
     est.generator = torch.Generator(device=dev).manual_seed(1000 + rank)
     opt = torch.optim.Adam(model.parameters(), lr=5e-4, fused=os.environ.get("FSN_FUSED_ADAM", "1") == "1")
     sched = ExponentialDecay(opt, 10000, 5e-4, r=0.1)
-    ro, rd = [], []
-    for pose in train_poses():  # dataset ray precompute on the device (llff.py:59-90)
-        o, d = U.get_rays(pose, (T_H, T_W, T_FOCAL), dev)
-        o, d = U.to_ndc(o.reshape(-1, 3), d.reshape(-1, 3), (T_H, T_W, T_FOCAL), 1.0)
-        ro.append(o)
-        rd.append(d)
-    ro, rd = torch.cat(ro), torch.cat(rd)
+    ro, rd, _ = U.build_rays(train_poses(), (T_H, T_W, T_FOCAL), dev, ndc=True)  # dataset precompute (llff.py:59-90)
     gt = torch.rand(ro.shape[0], 3, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
     gen = torch.Generator(device=dev).manual_seed(2000 + rank)  # every rank draws its own slice of the global batch
 

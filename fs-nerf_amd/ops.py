@@ -37,12 +37,17 @@ def _bk(bkgd) -> Optional[C.Array]:
 
 # ------------------------------------------------------------------ rays
 def get_rays(pose: Tensor, H: int, W: int, focal: float, device, row0: int = 0,
-             nrows: Optional[int] = None) -> Tuple[Tensor, Tensor]:
+             nrows: Optional[int] = None, out: Optional[Tuple[Tensor, Tensor]] = None) -> Tuple[Tensor, Tensor]:
+    """`out`: optional pre-allocated ([nrows*W,3], [nrows*W,3]) contiguous fp32 slices to write into."""
     nrows = H - row0 if nrows is None else nrows
     p = pose.detach().to("cpu", torch.float32)[:3, :4].contiguous()
     pose_host = (C.c_float * 12)(*p.reshape(-1).tolist())
-    o = torch.empty(nrows * W, 3, device=device, dtype=torch.float32)
-    d = torch.empty_like(o)
+    if out is None:
+        o = torch.empty(nrows * W, 3, device=device, dtype=torch.float32)
+        d = torch.empty_like(o)
+    else:
+        o, d = out
+        assert o.is_contiguous() and d.is_contiguous() and o.shape == (nrows * W, 3) and d.shape == o.shape
     with torch.cuda.device(o.device):
         L.check(L.lib().fsn_get_rays(pose_host, H, W, float(focal), row0, nrows, _p(o), _p(d), _stream()),
                 "fsn_get_rays")

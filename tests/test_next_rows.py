@@ -71,3 +71,26 @@ def test_to8b_and_render_path(golden_dir):
     img, dep = Rm.render_frame(hwf, 2.0, 6.0, poses[1], 480, est, m, white_bkgd=True, device=dev)
     np.testing.assert_array_equal(frames[1], img.cpu().numpy())
     np.testing.assert_array_equal(d_frames[1], dep.cpu().numpy())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ndc", [False, True])
+def test_build_rays_matches_the_dataset_recipe(ndc):
+    """row f4: all-pose ray precompute (+NDC, +aabb) against the reference's recipe evaluated with the oracle
+    (blender.py:174-191 / llff.py:59-90: stack of get_rays per pose, to_ndc(., 1.0), min/max of {o, o+d} / 8)."""
+    from fs_nerf_amd.utils import utilities as U
+    dev = torch.device("cuda:0")
+    hwf = (12, 16, 20.0)
+    poses = [O.pose_from_spherical(4.0, 40.0 + 5 * i, 30.0 * i) for i in range(5)]
+    ro, rd, aabb = U.build_rays(poses, hwf, dev, ndc=ndc)
+    wo = torch.cat([O.get_rays(p, hwf)[0].reshape(-1, 3) for p in poses])
+    wd = torch.cat([O.get_rays(p, hwf)[1].reshape(-1, 3) for p in poses])
+    if ndc:
+        wo, wd = O.to_ndc(wo, wd, hwf, 1.0)
+        ends = wo + wd
+        want = torch.cat([torch.minimum(wo.amin(0), ends.amin(0)), torch.maximum(wo.amax(0), ends.amax(0))]) / 8
+    else:
+        want = torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5])
+    assert ro.shape == (5 * 12 * 16, 3)
+    assert torch.allclose(ro.cpu(), wo, rtol=1e-5, atol=1e-5) and torch.allclose(rd.cpu(), wd, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(aabb.cpu(), want, rtol=1e-4, atol=1e-5)
