@@ -7,7 +7,8 @@ from .. import ops
 
 class OcclusionRegularizer:
     """Penalises density near the camera: mean over rays of sum_i w(t_i) sigma_i (loss.py:26-42),
-    w = -a t + b ('linear') or a exp(-b t) ('exp') (loss.py:44-60).  Forward only this round."""
+    w = -a t + b ('linear') or a exp(-b t) ('exp') (loss.py:44-60).  Differentiable w.r.t. sigmas
+    (the reference adds it to the training loss, run-nerf.py:264)."""
 
     def __init__(self, a: float, b: float, func: str = "linear"):
         assert a >= 0, "a should be non-negative"

@@ -203,6 +203,21 @@ __global__ void k_occl_mean(const float* __restrict__ sums, int64_t R, float* __
   if (threadIdx.x == 0) out[0] = s_sum[0] / (float)s_cnt[0];  // 0/0 = NaN like torch.mean of an empty stack
 }
 
+// backward of the occlusion regulariser w.r.t. sigmas: d sigma_i = g w(t_i) / #rays with samples
+__global__ void k_occl_count(const float* __restrict__ sums, int64_t R, int* __restrict__ cnt) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool ok = r < R && sums[r] == sums[r];
+  const uint64_t m = __ballot(ok);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(cnt, __popcll(m));
+}
+__global__ void k_occl_bwd(const float* __restrict__ t, int64_t N, float a, float b, int func,
+                           const float* __restrict__ g, const int* __restrict__ cnt, float* __restrict__ d_sig) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float w = func == 0 ? (-a * t[i] + b) : (a * expf(-b * t[i]));
+  d_sig[i] = g[0] * w / (float)cnt[0];
+}
+
 // to8b (src/render/rendering.py:21): (255 * clip(x,0,1)).astype(uint8) - truncation, like numpy
 __global__ void k_to8b(const float* __restrict__ x, int64_t n, uint8_t* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -342,6 +357,20 @@ extern "C" int fsn_occlusion_reg_fwd(const float* sigmas, const float* t_vals, c
   }
   k_occl_mean<<<1, 256, 0, as_stream(stream)>>>(ray_sums, n_rays, out);
   FSN_LAUNCH_CHECK("k_occl_mean");
+  return FSN_OK;
+}
+
+extern "C" int fsn_occlusion_reg_bwd(const float* t_vals, int64_t N, const float* ray_sums, int64_t n_rays, float a,
+                                     float b, int func, const float* d_out, int32_t* count_ws, float* d_sigmas,
+                                     fsn_stream_t stream) {
+  FSN_REQUIRE(N >= 0 && n_rays >= 0 && (func == 0 || func == 1), FSN_E_INVALID, "fsn_occlusion_reg_bwd: bad arguments");
+  if (N == 0) return FSN_OK;
+  FSN_REQUIRE(t_vals && ray_sums && d_out && count_ws && d_sigmas, FSN_E_INVALID, "fsn_occlusion_reg_bwd: null pointer");
+  FSN_HIP(hipMemsetAsync(count_ws, 0, sizeof(int32_t), as_stream(stream)));
+  k_occl_count<<<nblocks(n_rays, 256), 256, 0, as_stream(stream)>>>(ray_sums, n_rays, count_ws);
+  FSN_LAUNCH_CHECK("k_occl_count");
+  k_occl_bwd<<<nblocks(N, 256), 256, 0, as_stream(stream)>>>(t_vals, N, a, b, func, d_out, count_ws, d_sigmas);
+  FSN_LAUNCH_CHECK("k_occl_bwd");
   return FSN_OK;
 }
 

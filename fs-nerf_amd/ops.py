@@ -286,10 +286,36 @@ def render_fused(pm_coarse: Optional[PackedMLP], pm_fine: PackedMLP, rays_o: Ten
 
 
 # ------------------------------------------------------------------ "next" rows
+class _OcclusionRegFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sig, t, ri, n_rays, a, b, func):
+        N = sig.numel()
+        sums = torch.empty(max(n_rays, 1), device=sig.device, dtype=torch.float32)
+        out = torch.empty(1, device=sig.device, dtype=torch.float32)
+        with torch.cuda.device(sig.device):
+            L.check(L.lib().fsn_occlusion_reg_fwd(_p(sig), _p(t), _p(ri), N, n_rays, float(a), float(b), func, _p(sums),
+                                                  _p(out), _stream()), "fsn_occlusion_reg_fwd")
+        ctx.save_for_backward(t, sums)
+        ctx.cfg = (N, n_rays, float(a), float(b), func)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        t, sums = ctx.saved_tensors
+        N, n_rays, a, b, func = ctx.cfg
+        d_sig = torch.zeros(N, device=t.device, dtype=torch.float32)
+        cnt = torch.empty(1, device=t.device, dtype=torch.int32)
+        g = _f32(g, "grad").reshape(1)
+        with torch.cuda.device(t.device):
+            L.check(L.lib().fsn_occlusion_reg_bwd(_p(t), N, _p(sums), n_rays, a, b, func, _p(g), _p(cnt), _p(d_sig),
+                                                  _stream()), "fsn_occlusion_reg_bwd")
+        return d_sig, None, None, None, None, None, None
+
+
 def occlusion_reg(sigmas: Tensor, t_vals: Tensor, ray_idxs: Tensor, a: float, b: float, func: str = "linear",
                   n_rays: Optional[int] = None) -> Tensor:
-    """OcclusionRegularizer forward (src/core/loss.py:26-60) -> 0-dim tensor."""
-    sig, t = _f32(sigmas, "sigmas").reshape(-1), _f32(t_vals, "t_vals").reshape(-1)
+    """OcclusionRegularizer (src/core/loss.py:26-60) -> 0-dim tensor; differentiable w.r.t. sigmas."""
+    sig, t = _f32(sigmas, "sigmas").reshape(-1), _f32(t_vals.detach(), "t_vals").reshape(-1)
     ri = ray_idxs.contiguous()
     if ri.dtype != torch.int64:
         ri = ri.long()
@@ -298,13 +324,7 @@ def occlusion_reg(sigmas: Tensor, t_vals: Tensor, ray_idxs: Tensor, a: float, b:
         n_rays = int(ri[-1].item()) + 1 if N > 0 else 0
     if func not in ("linear", "exp"):
         raise ValueError(f"Unknown occlusion regularizer type: {func}")
-    sums = torch.empty(max(n_rays, 1), device=sig.device, dtype=torch.float32)
-    out = torch.empty(1, device=sig.device, dtype=torch.float32)
-    with torch.cuda.device(sig.device):
-        L.check(L.lib().fsn_occlusion_reg_fwd(_p(sig), _p(t), _p(ri), N, n_rays, float(a), float(b),
-                                              0 if func == "linear" else 1, _p(sums), _p(out), _stream()),
-                "fsn_occlusion_reg_fwd")
-    return out.reshape(())
+    return _OcclusionRegFn.apply(sig, t, ri, n_rays, a, b, 0 if func == "linear" else 1)
 
 
 def to8b(x: Tensor) -> Tensor:

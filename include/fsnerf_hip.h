@@ -172,6 +172,11 @@ int fsn_occlusion_reg_fwd(const float* sigmas, const float* t_vals, const int64_
                           int64_t n_rays, float a, float b, int func, float* ray_sums, float* out,
                           fsn_stream_t stream);
 
+/* backward of fsn_occlusion_reg_fwd w.r.t. sigmas: d_sigmas[i] = *d_out * w(t_i) / #rays with samples.  ray_sums is
+ * the forward's workspace (NaN marks rays without samples); count_ws: one int32 of device scratch. */
+int fsn_occlusion_reg_bwd(const float* t_vals, int64_t N, const float* ray_sums, int64_t n_rays, float a, float b,
+                          int func, const float* d_out, int32_t* count_ws, float* d_sigmas, fsn_stream_t stream);
+
 /* f1: the training step around the path.                         src/run-nerf.py:243-285, models.py:111-143
  * NeRF.forward keeping what its backward needs in a caller-provided workspace, and that backward (gradients of
  * every parameter; sample positions / directions receive none on this path).

@@ -94,3 +94,28 @@ def test_build_rays_matches_the_dataset_recipe(ndc):
     assert ro.shape == (5 * 12 * 16, 3)
     assert torch.allclose(ro.cpu(), wo, rtol=1e-5, atol=1e-5) and torch.allclose(rd.cpu(), wd, rtol=1e-5, atol=1e-5)
     assert torch.allclose(aabb.cpu(), want, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("func", ["linear", "exp"])
+def test_occlusion_regularizer_gradient(func):
+    """loss += occ_reg(sigmas, t_vals, ray_indices) (run-nerf.py:264): gradient w.r.t. sigmas vs autograd on the
+    reference formula (loss.py:39-42), rays without samples excluded from the mean."""
+    from fs_nerf_amd.core.loss import OcclusionRegularizer
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(3)
+    counts = torch.tensor([5, 0, 17, 1, 0, 64, 130])
+    ri = torch.repeat_interleave(torch.arange(len(counts)), counts)
+    N = ri.numel()
+    sig = (torch.rand(N, generator=gen) * 3 - 0.5)
+    t = torch.rand(N, generator=gen) * 4 + 2
+    s_gpu = sig.to(dev).requires_grad_(True)
+    reg = OcclusionRegularizer(0.3, 1.7, func)
+    out = reg(s_gpu, t.to(dev), ri.to(dev))
+    (out * 2.5).backward()
+    s64 = sig.double().requires_grad_(True)
+    w = (-0.3 * t.double() + 1.7) if func == "linear" else 0.3 * torch.exp(-1.7 * t.double())
+    want = torch.stack([(w[ri == v] * s64[ri == v]).sum() for v in torch.unique_consecutive(ri)]).mean()
+    (want * 2.5).backward()
+    assert abs(float(out) - float(want)) < 1e-5 * max(1.0, abs(float(want)))
+    assert torch.allclose(s_gpu.grad.cpu().double(), s64.grad, rtol=1e-5, atol=1e-7)
