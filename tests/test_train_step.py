@@ -83,6 +83,32 @@ def test_nerf_gradients_vs_autograd(n_layers, d_hidden, skip, nf, nfd, cscale, t
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tp", ["bf16", "fp16"])
+def test_single_pass_training_modes_run(tp):
+    """The single-pass 16-bit modes of the training kernels (BASELINE config 5 style: bf16 weights/activations): not a
+    parity mode (2^-8 / 2^-11 per product, ReLU units change branch), so the check is direction and scale of the
+    whole gradient against the fp32 path."""
+    from fs_nerf_amd.core.models import NeRF
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    m = NeRF(3, 3, 8, 256, (4,), pos_fn={"n_freqs": 10, "log_space": True}, dir_fn={"n_freqs": 4, "log_space": True})
+    m = m.to(dev).train()
+    N = 3000
+    x = torch.rand(N, 3, device=dev) * 2 - 1
+    d = torch.nn.functional.normalize(torch.randn(N, 3, device=dev), dim=-1)
+    c = torch.randn(N, 4, device=dev)
+    flat = {}
+    for mode in ("fp32", tp):
+        m.train_precision = mode
+        m.zero_grad(set_to_none=True)
+        (m(x, d) * c).sum().backward()
+        flat[mode] = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).double()
+    assert bool(torch.isfinite(flat[tp]).all())
+    cos = float((flat[tp] * flat["fp32"]).sum() / (flat[tp].norm() * flat["fp32"].norm()))
+    assert cos > 0.995 and abs(float(flat[tp].norm() / flat["fp32"].norm()) - 1.0) < 0.05, cos
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n", [1, 5, 129])
 def test_nerf_gradients_tiny_batches(n):
     """Fewer samples than one 128-sample tile / one more than a tile: padded columns must contribute nothing."""
