@@ -44,6 +44,29 @@ def test_argument_validation_without_gpu():
     assert lib.fsn_render_rays_fused(C.byref(desc), 2, None, None, C.byref(a), None) < 0
 
 
+def test_training_and_occgrid_entry_points_validate_without_gpu():
+    lib = L.lib()
+    from fs_nerf_amd import ops
+    d = ops.make_desc(8, 256, (4,), [2.0 ** i for i in range(10)], [2.0 ** i for i in range(4)])
+    # workspace sizing needs no device: saved activations + gradients = 20 KB per sample on the MFMA path
+    n = 128 * 64
+    w_mfma = lib.fsn_nerf_train_workspace_floats(C.byref(d), L.FSN_PREC_FP16X3, n)
+    w_plain = lib.fsn_nerf_train_workspace_floats(C.byref(d), L.FSN_PREC_FP32, n)
+    assert w_mfma > 0 and w_plain > 0
+    assert 4.5e3 * n < w_mfma < 7e3 * n + 5e7 and w_mfma % 1024 == 0
+    assert lib.fsn_nerf_train_workspace_floats(C.byref(d), 9, n) < 0 and b"precision" in lib.fsn_last_error()
+    assert lib.fsn_nerf_train_workspace_floats(C.byref(d), L.FSN_PREC_FP16X3, -1) < 0
+    assert lib.fsn_nerf_train_fwd(C.byref(d), 7, None, None, None, None, None, None, 4, None, None, None) != 0
+    assert lib.fsn_nerf_train_bwd(C.byref(d), L.FSN_PREC_FP32, None, 0, None, None, None, None, None, None, None) != 0
+    aabb = (C.c_float * 6)(0, 0, 0, 1, 1, 1)
+    assert lib.fsn_occgrid_march(None, None, 5, aabb, 0, 1, None, 0.0, 1.0, 0.1, None, 8, None, None, None, None, None, None) != 0
+    assert b"resolution" in lib.fsn_last_error()
+    bad = (C.c_float * 6)(0, 0, 0, 1, -1, 1)
+    assert lib.fsn_occgrid_march(None, None, 5, bad, 16, 1, None, 0.0, 1.0, 0.1, None, 8, None, None, None, None, None, None) != 0
+    assert lib.fsn_occgrid_update(None, 64, None, None, 0, 0.95, None, None, None) != 0
+    assert lib.fsn_packed_visibility(None, None, None, None, 0, 0, 1e-4, 0.0, None, None) == 0  # empty: nothing to do
+
+
 def test_host_layer_has_no_cpu_fallback():
     from fs_nerf_amd.core.models import NeRF, PositionalEncoder
     from fs_nerf_amd.utils import utilities as U
