@@ -61,6 +61,9 @@ class _NerfTrainFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out):
+        if ctx.work is None:
+            raise RuntimeError("NeRF backward ran twice on one forward: the saved activations are released after the "
+                               "first pass (retain_graph is not supported on this path)")
         dW, db = ops.nerf_train_bwd(ctx.desc, ctx.prec, ctx.weights, ctx.work, ctx.out, d_out.contiguous())
         ctx.work = None
         db = [g.reshape(-1) for g in db]
