@@ -305,10 +305,27 @@ __device__ __forceinline__ void unit_mfma(const char* ubase, const Frag& b, f32x
   }
   return;
 #endif
-#ifdef FSN_ABL_LDSDUMMY  // timing experiment: the LDS reads are issued but nothing depends on them
+#ifdef FSN_ABL_LDSDUMMY  // timing experiment: LDS reads are issued but no MFMA depends on them
   {
+    // FSN_ABL_LDSDUMMY = 1: the kernel's two 16-byte reads; 2: one 16-byte read; 3: two 8-byte reads; 4: four 8-byte
+#if FSN_ABL_LDSDUMMY == 1
     const s16x8 dh = *reinterpret_cast<const s16x8*>(ubase);
     const s16x8 dl = *reinterpret_cast<const s16x8*>(ubase + 1024);
+#elif FSN_ABL_LDSDUMMY == 2
+    const s16x8 dh = *reinterpret_cast<const s16x8*>(ubase);
+    const int dl = 0;
+#elif FSN_ABL_LDSDUMMY == 3
+    typedef __attribute__((ext_vector_type(2))) int i32x2;
+    const i32x2 dh = *reinterpret_cast<const i32x2*>(ubase - (threadIdx.x & 63) * 8);
+    const i32x2 dl = *reinterpret_cast<const i32x2*>(ubase - (threadIdx.x & 63) * 8 + 1024);
+#else
+    typedef __attribute__((ext_vector_type(2))) int i32x2;
+    const i32x2 dh = *reinterpret_cast<const i32x2*>(ubase - (threadIdx.x & 63) * 8);
+    const i32x2 dl = *reinterpret_cast<const i32x2*>(ubase - (threadIdx.x & 63) * 8 + 512);
+    const i32x2 d2 = *reinterpret_cast<const i32x2*>(ubase - (threadIdx.x & 63) * 8 + 1024);
+    const i32x2 d3 = *reinterpret_cast<const i32x2*>(ubase - (threadIdx.x & 63) * 8 + 1536);
+    asm volatile("" ::"v"(d2), "v"(d3));
+#endif
     acc = mfma16<F16>(b.lo, b.hi, acc);
     if (X3) {
       acc = mfma16<F16>(b.hi, b.hi, acc);
@@ -408,7 +425,7 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
           const int u = (tp * KS + ks) * 2 + sub;
           if (((u + kLead) % UPP == 0 && u + kLead <= TOTAL) || (u + kLead == TOTAL && TOTAL % UPP != 0)) st.open_next();
           if (u % UPP == 0) st.enter_phase();
-          const int v = u + 1;
+          const int v = u + 1;  // (two units ahead was measured too: no faster)
           const char* src = (v < TOTAL) ? ((v / UPP == u / UPP) ? st.c_base : st.n_base) + (v % UPP) * UB
                                         : st.n_base + (v - TOTAL) * UB;
           AFrag nxt;
