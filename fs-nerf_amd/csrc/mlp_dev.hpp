@@ -392,6 +392,11 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
       acc1 = *reinterpret_cast<const f32x4*>(bias + 32 * tp + 16 + 4 * g);
     }
     hk.pre(tp);
+#if defined(FSN_PRIO) && FSN_PRIO == 1
+    __builtin_amdgcn_s_setprio(1);
+#elif defined(FSN_PRIO) && FSN_PRIO == 2
+    __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const Frag& b = ks < KS_ACT ? act[ks < KS_ACT ? ks : 0] : enc[ks >= KS_ACT ? ks - KS_ACT : 0];
@@ -451,6 +456,11 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
       }
     }
     // ---- epilogue of pair tp
+#if defined(FSN_PRIO) && FSN_PRIO == 1
+    __builtin_amdgcn_s_setprio(0);
+#elif defined(FSN_PRIO) && FSN_PRIO == 2
+    __builtin_amdgcn_s_setprio(1);
+#endif
     float v[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { v[j] = acc0[j]; v[4 + j] = acc1[j]; }
