@@ -396,6 +396,8 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
     __builtin_amdgcn_s_setprio(1);
 #elif defined(FSN_PRIO) && FSN_PRIO == 2
     __builtin_amdgcn_s_setprio(0);
+#elif defined(FSN_PRIO) && FSN_PRIO == 4
+    if (threadIdx.x & 256) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
 #endif
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -460,6 +462,8 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
     __builtin_amdgcn_s_setprio(0);
 #elif defined(FSN_PRIO) && FSN_PRIO == 2
     __builtin_amdgcn_s_setprio(1);
+#elif defined(FSN_PRIO) && FSN_PRIO == 4
+    __builtin_amdgcn_s_setprio(2);
 #endif
     float v[8];
 #pragma unroll

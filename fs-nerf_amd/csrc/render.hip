@@ -7,9 +7,10 @@
 // group to ray group; per-ray scans/reductions are done by one wavefront per ray (ray_dev.hpp).
 // HBM traffic is the rays in and the requested outputs out.
 #include "common.hpp"
-// wave priority: raised for the per-pair epilogue (conversions), lowered for the MFMA k-loop: +1.3 % in this kernel
-// (A/B on MI355X; the standalone MLP kernel loses 1.6 % with either polarity and leaves it off)
-#define FSN_PRIO 2
+// wave priority (s_setprio): 2 for the per-pair epilogue (conversions), and in the MFMA k-loop 1 for waves 4..7 / 0 for
+// waves 0..3 (waves w and w+4 share a SIMD): +1.3 % and a further +0.5 % in this kernel (A/B on MI355X; the standalone
+// MLP kernel loses 1.6 % with priority changes and leaves them off)
+#define FSN_PRIO 4
 #include "mlp_dev.hpp"
 #include "ray_dev.hpp"
 
