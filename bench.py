@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — rendered rays/sec of the fused HIP ray-rendering path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N=1 directly; N>1 under torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N=1 runs in this process.  N>1: under `python -m torch.distributed.run --nproc-per-node N ...` (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in the environment) every process is one rank; started plainly, `bench.py --gpus N` is its own
+launcher: before anything touches the GPU it starts N fresh child processes (one per GPU, rendezvous on 127.0.0.1),
+relays rank 0's JSON line and exits non-zero if any rank failed.
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): synthetic Lego-style
 orbit, 800x800 frames (focal 1111.11, near 2, far 6), 64 coarse + 128 importance samples per ray
@@ -194,6 +199,117 @@ def train_main(args, rank, world, dev, dist, backend):
         print(json.dumps(line), flush=True)
 
 
+# ---------------------------------------------------------------- N>1 self-launcher
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv, timeout_s=None):
+    """Start `n` fresh child processes of this script, one rank each (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT set per child), wait for all of them, relay rank 0's stdout.  The parent never touches the GPU (it
+    must not: a process that has initialised HIP is not allowed to be replaced or to fork workers on this pool).
+    Returns the exit code: 0 iff every rank exited 0."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FSN_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    t_end = None if timeout_s is None else time.time() + timeout_s
+    rc = 0
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            break  # a rank died: the others would wait for it in the rendezvous / a collective forever
+        if t_end is not None and time.time() > t_end:
+            rc = 124
+            break
+        time.sleep(0.1)
+    for p in procs:
+        if p.poll() is None:
+            p.kill()
+            p.wait()
+    reader.join(timeout=10)
+    out0 = "".join(c for c in chunks if c)
+    for r, p in enumerate(procs):
+        if p.returncode not in (0, -9):  # -9: killed above because another rank had failed
+            rc = rc or (p.returncode if p.returncode > 0 else 1)
+            print(f"bench.py: rank {r} exited with code {p.returncode}", file=sys.stderr, flush=True)
+    if rc == 0 and any(p.returncode != 0 for p in procs):
+        rc = 1
+    if rc == 0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+    return rc
+
+
+def dry_run(args, rank, world):
+    """Launcher self-test (no GPU work, NOT a measurement): every rank joins a gloo group on the CPU, the max-over-ranks
+    reduction used for timing is exercised, rank 0 prints one JSON line describing what each rank saw."""
+    import torch.distributed as dist
+    seen = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "world": world}
+    if os.environ.get("FSN_BENCH_FAIL_RANK") == str(rank):
+        raise SystemExit(3)
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    ranks = torch.zeros(world, dtype=torch.int64)
+    ranks[rank] = 1 + int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group("gloo")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ranks, op=dist.ReduceOp.SUM)
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "max_over_ranks": float(t.item()), "local_ranks_plus_1": ranks.tolist(), **seen}), flush=True)
+
+
+def csrc_sha():
+    """Hash of the kernel sources the fused launch is built from: a PMC summary is only quoted when it was collected
+    on exactly this code."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "fs-nerf_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(precision):
+    """HBM-side bytes per fused launch from the committed rocprofv3 PMC passes (tools/run_pmc.sh ->
+    tools/summarize_pmc.py -> profiles/*_pmc_summary.json).  Returned only when the summary was collected for this
+    precision mode on exactly these kernel sources; otherwise null + the reason (never a stale number)."""
+    import glob
+    best = None
+    for pj in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
+        try:
+            j = json.load(open(pj))
+        except Exception:
+            continue
+        if j.get("kernel") != "k_render_fused" or j.get("precision") != precision:
+            continue
+        best = (pj, j)
+        if j.get("csrc_sha") == csrc_sha() and j.get("hbm_bytes_per_launch") is not None:
+            return j["hbm_bytes_per_launch"], {"file": os.path.relpath(pj, ROOT), "csrc_sha": j["csrc_sha"],
+                                                "precision": precision, "l2_hit_rate": j.get("l2_hit_rate")}
+    if best is None:
+        return None, {"note": f"no PMC summary for precision {precision} under profiles/"}
+    return None, {"note": "kernel sources changed since " + os.path.relpath(best[0], ROOT) + " was collected",
+                  "stale_value": best[1].get("hbm_bytes_per_launch")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,6 +318,7 @@ def main():
     ap.add_argument("--workload", choices=("render", "train"), default="render")
     ap.add_argument("--precision", default=os.environ.get("FSN_BENCH_PREC", "fp16x3"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="launcher self-test on the CPU (gloo); not a measurement")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 3 if args.workload == "render" else 20
@@ -211,8 +328,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly: become the launcher (nothing in this process has touched the GPU)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start {args.gpus} ranks (or none, and let "
+                         f"bench.py launch them)")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs the GPU (no CPU fallback)"
     local = local % max(torch.cuda.device_count(), 1)  # (rehearsals put several ranks on one card)
     torch.cuda.set_device(local)
@@ -281,13 +404,7 @@ def main():
         rays = world * args.steps * H * W
         value = rays / dt
         achieved = FLOP_PER_RAY * H * W / (kern_ms * 1e-3) / 1e12
-        traffic = None
-        pj = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if os.path.exists(pj):
-            try:
-                traffic = json.load(open(pj)).get("k_render_fused_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_src = measured_traffic(args.precision)
         line = {
             "metric": "rendered rays/sec (64+128 samples/ray, 8x256 MLP)", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -298,7 +415,7 @@ def main():
                                    "one fused launch per 640,000-ray frame incl. get_rays",
                        "rays_per_step": H * W, "parallelism": f"rays x{world} (no data-path collective)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_TFLOPS, "traffic": traffic,
+                         "frac": achieved / PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_render_fused", "kernel_ms": kern_ms, "flop_per_ray": FLOP_PER_RAY},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -7,9 +7,17 @@ Parameters are ordinary nn.Linear modules under the reference's attribute names,
 `state_dict()` loads unchanged (keys layers.N.*, sigma.*, connection.*, branch.*, rgb.*).
 `forward` never touches them with torch ops: they are packed into the MFMA streaming layout
 (re-packed whenever a parameter's version counter changes) and the whole network runs in the
-fused kernel `fsn_mlp_fwd`.  In training mode with autograd enabled, `forward(x, dirs)` runs the
-first-version training path instead (`_NerfTrainFn`: fp32 activations kept, library GEMMs).  Additions over the reference: an optional frequency mask
-(`set_freq_mask`) and the arithmetic mode (`precision`: "bf16x3" ~fp32 accuracy, "bf16" fast).
+fused kernel `fsn_mlp_fwd`.  In training mode with autograd enabled, `forward(x, dirs)` runs the training pair
+instead (`_NerfTrainFn`: `fsn_nerf_train_fwd` / `_bwd`, hand-written MFMA forward-with-savers, dgrad chain and
+split-K wgrad kernels in the same precision mode).  Additions over the reference: an optional frequency mask
+(`set_freq_mask`) and the arithmetic mode `precision`:
+  "fp16x3" (default) three fp16 MFMA passes on high/low parts, fp32 accumulate: fp32-class accuracy (the 1e-4
+            parity mode).  Representable range of fp16: |activation|, |weight| < 65504.  The kernels raise a device
+            flag when a hidden activation leaves that range; `forward` / `render_rays` then re-run the call in
+            "bf16x3" and keep that mode (a RuntimeWarning is issued) - inf/NaN are never returned silently;
+  "bf16x3"  the same split on bf16 parts: no range limit, ~1e-5 per product;
+  "fp16x2"  two passes (weights high part only): measured accuracy in DESIGN.md, not a parity mode;
+  "bf16" / "fp16"  one pass (BASELINE config 5), tolerance stated in the tests.
 """
 from typing import Optional, Sequence, Tuple
 

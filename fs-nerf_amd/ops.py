@@ -24,6 +24,16 @@ def _f32(t: Tensor, name: str) -> Tensor:
     return t.contiguous()
 
 
+def _i64(t: Tensor, name: str) -> Tensor:
+    """ray_indices as the kernels read them: int64 (the reference contract, rendering.py:66,92), on the GPU,
+    contiguous.  nerfacc-style callers may hand int32 indices: they are widened here, never reinterpreted."""
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback)")
+    if t.dtype not in (torch.int64, torch.int32, torch.int16, torch.uint8, torch.int8):
+        raise TypeError(f"{name}: expected an integer tensor, got {t.dtype}")
+    return t.to(torch.int64).contiguous()
+
+
 def _p(t: Optional[Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -390,7 +400,7 @@ def nerf_train_bwd(desc: L.MlpDesc, prec: int, weights: Sequence[Tensor], work: 
 def composite_packed_bwd(sigmas, rgbs, t_starts, t_ends, ray_indices, n_rays, bkgd, d_colors, d_opacity):
     sig, rgb = _f32(sigmas, "sigmas"), _f32(rgbs, "rgbs")
     t0, t1 = _f32(t_starts, "t_starts"), _f32(t_ends, "t_ends")
-    ri = ray_indices.contiguous()
+    ri = _i64(ray_indices, "ray_indices")
     N = sig.numel()
     dc = _f32(d_colors, "d_colors")
     dop = None if d_opacity is None else _f32(d_opacity, "d_opacity").reshape(-1)
@@ -434,7 +444,7 @@ def packed_visibility(sigmas: Tensor, t_starts: Tensor, t_ends: Tensor, ray_indi
     N = sig.numel()
     keep = torch.zeros(N, device=sig.device, dtype=torch.uint8)
     with torch.cuda.device(sig.device):
-        L.check(L.lib().fsn_packed_visibility(_p(sig), _p(t0), _p(t1), _p(ray_indices.contiguous()), N, int(n_rays),
+        L.check(L.lib().fsn_packed_visibility(_p(sig), _p(t0), _p(t1), _p(_i64(ray_indices, "ray_indices")), N, int(n_rays),
                                               float(early_stop_eps), float(alpha_thre), _p(keep), _stream()),
                 "fsn_packed_visibility")
     return keep.bool()

@@ -100,12 +100,21 @@ def rendering(t_starts: Tensor, t_ends: Tensor, ray_indices: Tensor, n_rays: int
     rgbs, sigmas = rgb_sigma_fn(t_starts, t_ends, ray_indices)
     assert rgbs.shape[-1] == 3, "rgbs must have 3 channels, got {}".format(rgbs.shape)
     assert sigmas.shape == t_starts.shape, "sigmas must have shape of (N,)! Got {}".format(sigmas.shape)
+    # A background that itself requires grad (the reference builds `render_bkgd` with requires_grad=train,
+    # rendering.py:86, which is what keeps loss.backward() legal on an all-background batch) is added with the
+    # compositor's own op sequence, colors + bkgd * (1 - opacity), as differentiable torch ops on [n_rays,3].
+    bk_grad = render_bkgd is not None and torch.is_grad_enabled() and render_bkgd.requires_grad
+    kernel_bk = None if bk_grad else render_bkgd
     if torch.is_grad_enabled() and (rgbs.requires_grad or sigmas.requires_grad):
-        bk = None if render_bkgd is None else [float(v) for v in render_bkgd.detach().cpu().tolist()]
+        bk = None if kernel_bk is None else [float(v) for v in kernel_bk.detach().cpu().tolist()]
         colors, opacity, depth, w, a, tr = _CompositeFn.apply(sigmas, rgbs.contiguous(), t_starts, t_ends,
                                                              ray_indices, n_rays, bk)
-        return colors, opacity, depth, {"weights": w, "alphas": a, "trans": tr, "sigmas": sigmas, "rgbs": rgbs}
-    return ops.composite_packed(sigmas, rgbs, t_starts, t_ends, ray_indices, n_rays, render_bkgd)
+        ex = {"weights": w, "alphas": a, "trans": tr, "sigmas": sigmas, "rgbs": rgbs}
+    else:
+        colors, opacity, depth, ex = ops.composite_packed(sigmas, rgbs, t_starts, t_ends, ray_indices, n_rays, kernel_bk)
+    if bk_grad:
+        colors = colors + render_bkgd.to(colors.dtype) * (1.0 - opacity)
+    return colors, opacity, depth, ex
 
 
 def render_rays(rays_o: Tensor, rays_d: Tensor, estimator, model: nn.Module, train: bool = False,
@@ -165,7 +174,7 @@ def render_rays(rays_o: Tensor, rays_d: Tensor, estimator, model: nn.Module, tra
             out = fine(x, td)
             return out[..., :3], out[..., -1]
 
-        render_bkgd = white_bkgd * torch.ones((3,), device=device)
+        render_bkgd = white_bkgd * torch.ones((3,), device=device, requires_grad=train)  # rendering.py:86
         try:
             output = rendering(t_starts, t_ends, ray_indices, n_rays=len(rays_o), rgb_sigma_fn=rgb_sigma_fn,
                                render_bkgd=render_bkgd)

@@ -46,24 +46,77 @@ def gather_rows(local: torch.Tensor, H: int) -> torch.Tensor:
     return torch.cat([parts[r][: shard_rows(H, r, world)[1]] for r in range(world)], dim=0)
 
 
-def allreduce_grads(params, average: bool = True) -> None:
+class FlatGrads:
+    """ONE persistent flat fp32 gradient bucket for a FIXED parameter list (identical on every rank: same model,
+    same order), with every `p.grad` a view into it.  Autograd accumulates into the views in place, the data-parallel
+    synchronisation is a single all-reduce of `flat` with no concatenation or copy-back, and a flat optimizer
+    (core/optim.py:FusedAdam) reads the same memory.  A parameter whose gradient is missing (`None`) contributes
+    zeros, so every rank always enters the collective with the same bucket size."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatGrads: no trainable parameters")
+        dev = self.params[0].device
+        self.offsets, n = [], 0
+        for p in self.params:
+            if p.device != dev or p.dtype != torch.float32:
+                raise ValueError("FlatGrads: parameters must be float32 on one device")
+            self.offsets.append(n)
+            n += p.numel()
+        self.numel = n
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.bind()
+
+    def view(self, i: int) -> torch.Tensor:
+        p = self.params[i]
+        return self.flat[self.offsets[i]:self.offsets[i] + p.numel()].view_as(p)
+
+    def bind(self) -> None:
+        """(Re)attach: gradients that autograd or the caller replaced are copied into the bucket, missing ones
+        become zeros, and `p.grad` is pointed at the bucket again."""
+        for i, p in enumerate(self.params):
+            v = self.view(i)
+            g = p.grad
+            if g is None:
+                v.zero_()
+            elif g.data_ptr() != v.data_ptr() or g.stride() != v.stride():
+                v.copy_(g)
+            p.grad = v
+
+    def zero(self) -> None:
+        """`optimizer.zero_grad(set_to_none=False)` for the whole model in one fill."""
+        self.flat.zero_()
+        self.bind()
+
+    def allreduce(self, average: bool = True) -> None:
+        self.bind()
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        flat = self.flat
+        if flat.is_cuda and dist.get_backend() == "gloo":  # CPU rehearsal backend: stage through host memory
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if average:
+            flat.div_(dist.get_world_size())
+
+
+_buckets = {}
+
+
+def allreduce_grads(params, average: bool = True) -> FlatGrads:
     """Data-parallel gradient synchronisation (north_star: "an RCCL all-reduce of the gradient over xGMI and
     nothing else"): ONE all-reduce(sum) of one flat fp32 bucket holding every gradient (595,844 floats = 2.38 MB
-    for an 8x256 NeRF; the message is latency-bound on xGMI, so no per-layer hooks or bucketing), then x 1/world."""
-    params = [p for p in params if p.grad is not None]
-    if not params or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return
-    flat = torch.cat([p.grad.reshape(-1) for p in params])
-    if flat.is_cuda and dist.get_backend() == "gloo":  # CPU rehearsal backend: stage through host memory
-        host = flat.cpu()
-        dist.all_reduce(host, op=dist.ReduceOp.SUM)
-        flat.copy_(host)
-    else:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    if average:
-        flat.div_(dist.get_world_size())
-    off = 0
-    for p in params:
-        n = p.grad.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p.grad))
-        off += n
+    for an 8x256 NeRF; the message is latency-bound on xGMI, so no per-layer hooks or bucketing), then x 1/world.
+    The bucket (`FlatGrads`) is built once per parameter list and reused: the list is FIXED (every trainable
+    parameter, zeros where a gradient is missing), so all ranks always reduce the same number of elements."""
+    params = [p for p in params if p.requires_grad]
+    key = tuple(id(p) for p in params)
+    b = _buckets.get(key)
+    if b is None or any(a is not c for a, c in zip(b.params, params)):
+        b = _buckets[key] = FlatGrads(params)
+    b.allreduce(average)
+    return b

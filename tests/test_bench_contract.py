@@ -42,3 +42,46 @@ def test_train_line_contract():
     assert KEYS <= set(j) and j["steps"] == 3 and "trained rays/sec" in j["metric"]
     assert j["config"]["rays_per_step"] == 4096 and j["config"]["parallelism"].startswith("dp1")
     assert 0.0 < j["loss"] < 1.0 and j["value"] > 1e4
+
+
+# ---- the N>1 launcher (CPU: `--dry-run` children join a gloo group instead of touching the GPU)
+def _launch(*args, env=None):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                          timeout=600, cwd=ROOT, env=e)
+
+
+def test_self_launch_two_ranks_dry_run():
+    """`python bench.py --gpus 2` with no WORLD_SIZE starts 2 fresh ranks, wires RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* and relays exactly rank 0's JSON line."""
+    out = _launch("--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run")
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    j = json.loads(lines[0])
+    assert j["dry_run"] and j["n_gpus"] == 2 and j["world"] == 2 and j["rank"] == 0 and j["steps"] == 3
+    assert j["max_over_ranks"] == 2.0            # max over ranks of (1 + rank): both ranks joined the group
+    assert j["local_ranks_plus_1"] == [1, 2]     # every rank saw its own LOCAL_RANK
+
+
+def test_self_launch_propagates_rank_failure():
+    out = _launch("--gpus", "2", "--dry-run", env={"FSN_BENCH_FAIL_RANK": "1"})
+    assert out.returncode != 0 and "rank 1 exited" in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")], "no result line from a failed job"
+
+
+def test_world_size_mismatch_is_an_error():
+    out = _launch("--gpus", "4", "--dry-run", env={"WORLD_SIZE": "2", "RANK": "0"})
+    assert out.returncode != 0 and "WORLD_SIZE=2" in (out.stderr + out.stdout)
+
+
+def test_traffic_is_never_stale():
+    sys.path.insert(0, ROOT)
+    import bench
+    t, src = bench.measured_traffic("no-such-mode")
+    assert t is None and "note" in src
+    t, src = bench.measured_traffic("fp16x3")
+    assert (t is None and "note" in src) or src["csrc_sha"] == bench.csrc_sha()

@@ -118,10 +118,12 @@ def test_update_and_render_through_reference_call_shape():
     (rgb, opacity, depth, extras), ri, tv = Rm.render_rays(o, d, est, m, train=True, white_bkgd=True,
                                                            render_step_size=step, device=dev)
     assert ri.numel() == 0 and bool((rgb == 1.0).all()) and float(depth.abs().max()) == 0.0
-    if rgb.requires_grad:  # loss.backward() on the all-background batch must be legal, with zero gradients
-        torch.nn.functional.mse_loss(rgb, torch.zeros(256, 3, device=dev)).backward()
-        assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in m.parameters())
-        m.zero_grad(set_to_none=True)
+    # loss.backward() on the all-background batch is legal in the reference (render_bkgd requires grad when
+    # train=True, rendering.py:86) and leaves the network's gradients empty / zero
+    assert rgb.requires_grad
+    torch.nn.functional.mse_loss(rgb, torch.zeros(256, 3, device=dev)).backward()
+    assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in m.parameters())
+    m.zero_grad(set_to_none=True)
 
     def occ_eval_fn(x):
         return m(x) * step

@@ -341,3 +341,44 @@ def test_gradient_allreduce_two_ranks_gloo():
     # mean over ranks of (rank+1)*(i+1) = 1.5*(i+1), identical on both ranks, whole tensors updated
     for rank, vals, uniform in res:
         assert vals == [1.5, 3.0, 4.5, 6.0] and uniform
+
+
+def _dp_worker_ragged(rank, world, port, q):
+    """Ranks whose sets of defined gradients differ must still reduce the same bucket (zeros for the missing ones)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+        ps = list(net.parameters())
+        for i, p in enumerate(ps):
+            if (i + rank) % 2 == 0:  # rank 0 defines grads 0,2; rank 1 defines grads 1,3
+                p.grad = torch.full_like(p, float(10 * rank + i + 1))
+        b = shard.allreduce_grads(ps)
+        views_ok = all(p.grad.data_ptr() == b.view(i).data_ptr() for i, p in enumerate(ps))
+        # second step through autograd: accumulation lands in the bucket views, no cat / copy-back
+        b.zero()
+        net(torch.ones(2, 5)).sum().backward()
+        in_place = all(p.grad.data_ptr() == b.view(i).data_ptr() for i, p in enumerate(ps))
+        b.allreduce()
+        q.put((rank, [float(x) for x in b.flat[[0, 35, 42, 63]]] if False else
+               [float(ps[i].grad.flatten()[0]) for i in range(4)], views_ok and in_place, int(b.numel)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_allreduce_fixed_bucket_with_missing_grads_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker_ragged, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1], "ranks disagree after the all-reduce"
+    assert all(r[2] for r in res) and all(r[3] == 5 * 7 + 7 + 7 * 3 + 3 for r in res)

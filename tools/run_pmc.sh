@@ -2,7 +2,7 @@
 # Collect rocprofv3 PMC passes for the bench workload (run ON the GPU box via gpurun).
 # usage: bash tools/run_pmc.sh <tag> [bench args...]
 set -e
-TAG=${1:-r01}; shift || true
+TAG=${1:-r02}; shift || true
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
