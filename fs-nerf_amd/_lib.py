@@ -15,6 +15,8 @@ FSN_PREC_BF16 = 1
 FSN_PREC_FP16X3 = 2
 FSN_PREC_FP16 = 3
 FSN_PREC_FP32 = 4  # training only: plain fp32 library GEMMs
+FSN_PREC_FP16X2 = 6  # two passes (weights high part only), inference only
+FSN_STATUS_FP16_RANGE = 1
 
 
 class MlpDesc(C.Structure):
@@ -31,7 +33,7 @@ class RenderArgs(C.Structure):
                 ("colors", C.c_void_p), ("opacity", C.c_void_p), ("depth", C.c_void_p),
                 ("weights", C.c_void_p), ("alphas", C.c_void_p), ("trans", C.c_void_p),
                 ("sigmas", C.c_void_p), ("rgbs", C.c_void_p), ("edges_out", C.c_void_p),
-                ("weights_coarse", C.c_void_p)]
+                ("weights_coarse", C.c_void_p), ("status", C.c_void_p)]
 
 
 _vp, _i, _i64, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
@@ -53,13 +55,13 @@ SIGNATURES = {
     "fsn_mlp_blob_bytes": (_i64, [_PD, _i]),
     "fsn_mlp_pack": (_i, [_PD, _i, _vp, _vp, _vp, _vp]),
     "fsn_mlp_pack_host": (_i, [_PD, _i, _vp, _vp, _vp]),
-    "fsn_mlp_fwd": (_i, [_PD, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "fsn_mlp_fwd": (_i, [_PD, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "fsn_render_rays_fused": (_i, [_PD, _i, _vp, _vp, C.POINTER(RenderArgs), _vp]),
     "fsn_occlusion_reg_fwd": (_i, [_vp, _vp, _vp, _i64, _i64, _f, _f, _i, _vp, _vp, _vp]),
     "fsn_to8b": (_i, [_vp, _i64, _vp, _vp]),
     "fsn_nerf_train_workspace_floats": (_i64, [_PD, _i, _i64]),
-    "fsn_nerf_train_fwd": (_i, [_PD, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
-    "fsn_nerf_train_bwd": (_i, [_PD, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fsn_nerf_train_fwd": (_i, [_PD, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "fsn_nerf_train_bwd": (_i, [_PD, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fsn_occlusion_reg_bwd": (_i, [_vp, _i64, _vp, _i64, _f, _f, _i, _vp, _vp, _vp, _vp]),
     "fsn_occgrid_march": (_i, [_vp, _vp, _i64, _vp, _i, _i, _vp, _f, _f, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fsn_packed_visibility": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _f, _f, _vp, _vp]),

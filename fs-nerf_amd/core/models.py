@@ -19,6 +19,7 @@ split-K wgrad kernels in the same precision mode).  Additions over the reference
   "fp16x2"  two passes (weights high part only): measured accuracy in DESIGN.md, not a parity mode;
   "bf16" / "fp16"  one pass (BASELINE config 5), tolerance stated in the tests.
 """
+import warnings
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -63,7 +64,7 @@ class _NerfTrainFn(torch.autograd.Function):
         prec = model.train_prec()
         out, work = ops.nerf_train_fwd(desc, prec, weights, biases, x, dirs, model._mask(model.pos_mask, dev),
                                        model._mask(model.dir_mask, dev))
-        ctx.desc, ctx.prec, ctx.work, ctx.out = desc, prec, work, out
+        ctx.desc, ctx.prec, ctx.work, ctx.out, ctx.model = desc, prec, work, out, model
         ctx.weights = [w.detach() for w in weights]
         return out.reshape(*x.shape[:-1], 4)
 
@@ -74,13 +75,20 @@ class _NerfTrainFn(torch.autograd.Function):
                                "first pass (retain_graph is not supported on this path)")
         dW, db = ops.nerf_train_bwd(ctx.desc, ctx.prec, ctx.weights, ctx.work, ctx.out, d_out.contiguous())
         ctx.work = None
+        model = ctx.model
+        if model.range_check and model.fp16_family(ctx.prec) and not ops.range_ok(d_out.device):
+            # the forward's activations or the scaled gradients left the fp16 range: this step's gradients are not
+            # usable.  Like a loss-scaler's skipped step they are returned as zeros, and the model continues in bf16x3.
+            model.fall_back("training step")
+            dW, db = [torch.zeros_like(g) for g in dW], [torch.zeros_like(g) for g in db]
         db = [g.reshape(-1) for g in db]
         return (None, None, None, *dW, *db)
 
 
 class NeRF(nn.Module):
     PRECISIONS = {"bf16x3": L.FSN_PREC_BF16X3, "bf16": L.FSN_PREC_BF16, "fp16x3": L.FSN_PREC_FP16X3,
-                  "fp16": L.FSN_PREC_FP16}
+                  "fp16": L.FSN_PREC_FP16, "fp16x2": L.FSN_PREC_FP16X2}
+    FALLBACK = {"fp16x3": "bf16x3", "fp16x2": "bf16x3", "fp16": "bf16"}  # same pass structure, float32 range
 
     def __init__(self, d_pos: int = 3, d_dir: int = 3, n_layers: int = 8, d_hidden: int = 256,
                  skip: Tuple[int, ...] = (4,), precision: str = "fp16x3", **kwargs) -> None:
@@ -102,6 +110,7 @@ class NeRF(nn.Module):
         self.branch = nn.Linear(d_hidden + d_de, d_hidden // 2)
         self.rgb = nn.Linear(d_hidden // 2, 3)
         self.precision = precision
+        self.range_check = True  # fp16 modes: read the kernels' range flag back after each call (one host sync)
         self.train_precision: Optional[str] = None  # None: same mode as `precision`; "fp32": plain library GEMMs
         self.pos_mask: Optional[Tensor] = None
         self.dir_mask: Optional[Tensor] = None
@@ -115,7 +124,23 @@ class NeRF(nn.Module):
 
     def train_prec(self) -> int:
         tp = self.train_precision or self.precision
+        if tp == "fp16x2":
+            tp = "fp16x3"  # the two-pass mode is inference only
         return L.FSN_PREC_FP32 if tp == "fp32" else self.PRECISIONS[tp]
+
+    @staticmethod
+    def fp16_family(prec: int) -> bool:
+        return prec in (L.FSN_PREC_FP16X3, L.FSN_PREC_FP16, L.FSN_PREC_FP16X2)
+
+    def fall_back(self, what: str) -> None:
+        """An fp16-mode launch reported values outside the fp16 range (|v| >= 65504): continue in the bf16 mode of
+        the same pass structure, which has float32's range.  Never silent."""
+        new = self.FALLBACK.get(self.precision, "bf16x3")
+        warnings.warn(f"fs-nerf HIP path: {what}: hidden activations left the fp16 range in precision "
+                      f"'{self.precision}'; re-running / continuing in '{new}'", RuntimeWarning, stacklevel=3)
+        self.precision = new
+        if self.train_precision in self.FALLBACK:
+            self.train_precision = None
 
     def _tensors(self):
         mods = list(self.layers) + [self.sigma, self.connection, self.branch, self.rgb]
@@ -148,4 +173,8 @@ class NeRF(nn.Module):
             ws, bs = self._tensors()
             return _NerfTrainFn.apply(self, x, dirs, *ws, *bs)
         dev = x.device
-        return ops.mlp_fwd(self.packed(), x, dirs, self._mask(self.pos_mask, dev), self._mask(self.dir_mask, dev))
+        out = ops.mlp_fwd(self.packed(), x, dirs, self._mask(self.pos_mask, dev), self._mask(self.dir_mask, dev))
+        if self.range_check and self.fp16_family(self.PRECISIONS[self.precision]) and not ops.range_ok(dev):
+            self.fall_back("NeRF.forward")
+            out = ops.mlp_fwd(self.packed(), x, dirs, self._mask(self.pos_mask, dev), self._mask(self.dir_mask, dev))
+        return out

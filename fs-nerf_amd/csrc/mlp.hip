@@ -128,13 +128,14 @@ static int fill_pack_args(const fsn_mlp_desc* d, int prec, const float* const* W
   return FSN_OK;
 }
 
-static NetParams make_net_params(const fsn_mlp_desc& d, const NetGeom& G, const void* blob) {
+static NetParams make_net_params(const fsn_mlp_desc& d, const NetGeom& G, const void* blob, uint32_t* status) {
   NetParams p;
   p.blob = static_cast<const char*>(blob);
   p.aux_off = (int32_t)G.aux_off; p.aux_floats = G.aux_floats; p.stream_off = (int32_t)G.stream_off;
   p.nph_density = G.nph_density; p.nph_full = G.nph_full;
   p.n_layers = d.n_layers; p.skip_mask = d.skip_mask;
   p.n_freqs_pos = d.n_freqs_pos; p.n_freqs_dir = d.n_freqs_dir;
+  p.status = status;
   return p;
 }
 
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(kThreads) void k_mlp_fwd(MlpFwdArgs a) {
   st.init(smem, nullptr, 0, 0, sbase, (uint32_t)(full ? a.net.nph_full : a.net.nph_density), 1);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   ARing ring;
-  prime_ring<PREC>(st, ring);
+  prime_ring<PREC, NT>(st, ring);
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t s = tile * 128 + wave * 16 + (lane & 15);
     const int64_t sc = s < a.n ? s : a.n - 1;
@@ -256,7 +257,8 @@ extern "C" int fsn_mlp_pack_host(const fsn_mlp_desc* desc, int prec, const float
 }
 
 extern "C" int fsn_mlp_fwd(const fsn_mlp_desc* desc, int prec, const void* blob, const float* x, const float* dirs,
-                           const float* pos_mask, const float* dir_mask, int64_t n, float* out, fsn_stream_t stream) {
+                           const float* pos_mask, const float* dir_mask, int64_t n, float* out, uint32_t* status,
+                           fsn_stream_t stream) {
   FSN_REQUIRE(desc && n >= 0, FSN_E_INVALID, "fsn_mlp_fwd: bad arguments");
   NetGeom G;
   const char* why;
@@ -267,8 +269,9 @@ extern "C" int fsn_mlp_fwd(const fsn_mlp_desc* desc, int prec, const void* blob,
   FSN_REQUIRE(G.aux_floats <= kAuxCapFloats, FSN_E_UNSUPPORTED, "fsn_mlp_fwd: network too deep for the LDS aux area");
   const int cus = fsn_device_cus();
   if (cus <= 0) return FSN_E_HIP;
-  MlpFwdArgs a{make_net_params(*desc, G, blob), x, dirs, pos_mask, dir_mask, n, out};
+  MlpFwdArgs a{make_net_params(*desc, G, blob, status), x, dirs, pos_mask, dir_mask, n, out};
   hipStream_t s = as_stream(stream);
+  if (prec == FSN_PREC_FP16X2) return desc->d_hidden == 256 ? launch_mlp_fwd<8, 6>(a, cus, s) : launch_mlp_fwd<4, 6>(a, cus, s);
   const int key = (desc->d_hidden == 256 ? 4 : 0) + prec;
   switch (key) {
     case 0: return launch_mlp_fwd<4, 0>(a, cus, s);

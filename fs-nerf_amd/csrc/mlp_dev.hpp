@@ -17,6 +17,10 @@
 #pragma once
 #include "common.hpp"
 #include "mlp_layout.hpp"
+#include "kloop_gen.hpp"
+
+#include <type_traits>
+#include <utility>
 
 namespace fsn {
 
@@ -87,7 +91,8 @@ struct WStream {
   // offset of global_load_lds advances BOTH the global and the LDS address.
   __device__ __forceinline__ void stage() {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t m0v = ring_lds + s_slot * kPhaseBytes + wave * (kGldsPerWave * 1024);
+    // (readfirstlane: the value is wave-uniform, but the "s" constraint needs the compiler to know it)
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane(ring_lds + s_slot * kPhaseBytes + wave * (kGldsPerWave * 1024));
     const uint32_t voff = (threadIdx.x >> 6) * (kGldsPerWave * 1024) + (threadIdx.x & 63) * 16;
     const uint64_t sp = (uint64_t)s_ptr;
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sp);
@@ -140,6 +145,29 @@ struct WStream {
     c_slot = (c_slot + 1) & (kNSlot - 1);
   }
   __device__ __forceinline__ void enter_phase() { c_base = n_base; }
+  // ---- interface of the hand-scheduled k-loop blocks (kloop_gen.hpp), which carry the phase openings inside
+  // their instruction stream.  next_stage(): M0 value and global base of the next phase to stage, advancing the
+  // stager exactly as stage() does.  phase_lds(k): LDS byte address (+ 16*lane) of the k-th phase counted from the
+  // one opened last (k = 0).  opened(n): the block executed n openings.
+  __device__ __forceinline__ void next_stage(uint32_t& m0v, uint64_t& gbase) {
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    m0v = __builtin_amdgcn_readfirstlane(ring_lds + s_slot * kPhaseBytes + wave * (kGldsPerWave * 1024));
+    const uint64_t sp = (uint64_t)s_ptr;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sp);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(sp >> 32));
+    gbase = ((uint64_t)hi << 32) | lo;
+    s_ptr += kPhaseBytes;
+    s_slot = (s_slot + 1) & (kNSlot - 1);
+    if (--s_left == 0) advance_pass_();
+  }
+  __device__ __forceinline__ uint32_t phase_lds(uint32_t k) const {
+    return ring_lds + ((c_slot + kNSlot - 1 + k) & (kNSlot - 1)) * kPhaseBytes + (threadIdx.x & 63) * 16;
+  }
+  __device__ __forceinline__ void opened(uint32_t n) {
+    c_slot = (c_slot + n) & (kNSlot - 1);
+    n_base = ring + ((c_slot + kNSlot - 1) & (kNSlot - 1)) * kPhaseBytes + (threadIdx.x & 63) * 16;
+    c_base = n_base;
+  }
   // before the workgroup exits (or touches the ring for anything else)
   __device__ __forceinline__ void drain() {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -166,12 +194,54 @@ __device__ __forceinline__ float from_h(short b) {
 }
 template <bool F16, bool X3>
 __device__ __forceinline__ void split_store(const float v[8], Frag& f) {
+  if constexpr (F16 && X3) {
+    // fp16 high / low parts of a pair of values in three instructions: packed round-to-nearest convert, then
+    // low = fp16(v - float(high)) as one mixed-precision fma each (fp32 arithmetic on the fp16 high part, one
+    // rounding to fp16: the same value as the convert-back / subtract / convert sequence, which is exact until the
+    // last step).  Written as asm: hipcc folds fma(h, -1, v) back into a subtraction and then forms v_pk_add_f32.
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+    u32x4 h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t hh, ll;
+      asm("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+          "v_fma_mixlo_f16 %1, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+          "v_fma_mixhi_f16 %1, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+          : "=&v"(hh), "=&v"(ll)
+          : "v"(v[2 * i]), "v"(v[2 * i + 1]));
+      h[i] = hh;
+      l[i] = ll;
+    }
+    f.hi = __builtin_bit_cast(s16x8, h);
+    f.lo = __builtin_bit_cast(s16x8, l);
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const short h = to_h<F16>(v[j]);
     f.hi[j] = h;
     f.lo[j] = X3 ? to_h<F16>(v[j] - from_h<F16>(h)) : (short)0;
   }
+}
+
+// Range guard of the fp16 modes: running packed maximum of the |high part| bit patterns a wave has produced
+// (0x7c00 = infinity: the value left the fp16 range).  4 instructions per output pair.
+template <bool SIGNED>
+__device__ __forceinline__ void range_track(uint32_t& fmax, const s16x8& hi) {
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+  const u32x4 w = __builtin_bit_cast(u32x4, hi);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint32_t x = w[i];
+    if (SIGNED) x &= 0x7fff7fffu;
+    asm("v_pk_max_u16 %0, %0, %1" : "+v"(fmax) : "v"(x));
+  }
+}
+
+// a value reached fp16 infinity somewhere in this wave's tile: tell the host (never silent)
+__device__ __forceinline__ void range_report(uint32_t* status, uint32_t fmax) {
+  const bool bad = (fmax & 0xffffu) >= 0x7c00u || (fmax >> 16) >= 0x7c00u;
+  if (__builtin_amdgcn_readfirstlane((int)__any(bad)) && status) { if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
 
 // Network description as the kernel needs it (wave-uniform).  Aux offsets follow build_geom():
@@ -183,6 +253,7 @@ struct NetParams {  // host -> kernel argument
   int32_t n_layers;
   uint32_t skip_mask;
   int32_t n_freqs_pos, n_freqs_dir;
+  uint32_t* status;  // device word or null: bit 0 is set when a hidden activation leaves the fp16 range
 };
 
 struct NetDev {
@@ -192,6 +263,7 @@ struct NetDev {
   int32_t n_layers;
   uint32_t skip_mask;
   int32_t n_freqs_pos, n_freqs_dir;
+  uint32_t* status;
 };
 
 // sin and cos of a float32 argument, branch-free: Cody-Waite reduction by pi/2 in three fma
@@ -261,6 +333,7 @@ enum : int { EPI_RELU_CVT = 0, EPI_LAST_FULL = 1, EPI_LAST_DENS = 4, EPI_CVT = 2
 struct Heads {
   float sigma;  // partial dot (this lane group's features)
   float rgb[3];
+  uint32_t fmax;  // fp16 modes: packed running max of |activation high part| bits (range guard)
 };
 
 // One unit: this wave's 16-sample slice of  acc[16 out x 16 samples] += W_unit[16 x 32] . act[32 x 16]
@@ -277,19 +350,19 @@ struct AFrag {  // A operand (weights) of one unit
 // carries over from GEMM to GEMM, tile to tile and pass to pass: on entry to a GEMM `cur` holds its
 // units 0 and 1.
 struct ARing {
-  AFrag cur[2];
+  AFrag cur[3];  // [2]: third set of the hand-scheduled x3 k-loop's rotation
 };
 template <int PREC>
 __device__ __forceinline__ void load_afrag(const char* p, AFrag& f) {
   f.hi = *reinterpret_cast<const s16x8*>(p);
-  if ((PREC & 1) == 0) f.lo = *reinterpret_cast<const s16x8*>(p + 1024);
+  if ((PREC & 1) == 0 && PREC != 6) f.lo = *reinterpret_cast<const s16x8*>(p + 1024);
 }
 template <int PREC>
 __device__ __forceinline__ void unit_mfma_r(const AFrag& a, const Frag& b, f32x4& acc) {
   constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
   acc = mfma16<F16>(a.hi, b.hi, acc);
   if (X3) {
-    acc = mfma16<F16>(a.lo, b.hi, acc);
+    if (PREC != 6) acc = mfma16<F16>(a.lo, b.hi, acc);  // (fp16x2: the weights' low parts are dropped)
     acc = mfma16<F16>(a.hi, b.lo, acc);
   }
 }
@@ -338,8 +411,10 @@ __device__ __forceinline__ void unit_mfma(const char* ubase, const Frag& b, f32x
   const s16x8 ah = *reinterpret_cast<const s16x8*>(ubase);
   acc = mfma16<F16>(ah, b.hi, acc);
   if (X3) {
-    const s16x8 al = *reinterpret_cast<const s16x8*>(ubase + 1024);
-    acc = mfma16<F16>(al, b.hi, acc);
+    if (PREC != 6) {
+      const s16x8 al = *reinterpret_cast<const s16x8*>(ubase + 1024);
+      acc = mfma16<F16>(al, b.hi, acc);
+    }
     acc = mfma16<F16>(ah, b.lo, acc);
   }
 }
@@ -357,6 +432,171 @@ struct NoHook {
   __device__ __forceinline__ void pre(int) {}
   __device__ __forceinline__ void post(int, float (&)[8]) {}
 };
+
+// Epilogue of one finished output pair (shared by the compiler-scheduled and the hand-scheduled k-loops).
+template <int PREC, int NP_OUT, int EPI, int NOUT, class HK>
+__device__ __forceinline__ void pair_epilogue(const NetDev& net, int tp, const f32x4& acc0, const f32x4& acc1,
+                                              Frag (&out)[NOUT], Heads& heads, int g, HK& hk) {
+  constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
+#if defined(FSN_PRIO) && FSN_PRIO == 1
+    __builtin_amdgcn_s_setprio(0);
+#elif defined(FSN_PRIO) && FSN_PRIO == 2
+    __builtin_amdgcn_s_setprio(1);
+#elif defined(FSN_PRIO) && FSN_PRIO == 4
+    __builtin_amdgcn_s_setprio(2);
+#endif
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = acc0[j]; v[4 + j] = acc1[j]; }
+    if (EPI != EPI_CVT && EPI != EPI_NONE) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = relu_f32(v[j]);
+    }
+    hk.post(tp, v);
+    if (EPI == EPI_LAST_FULL || EPI == EPI_LAST_DENS) {
+      const float* ws = net.aux + (net.n_layers + 2) * (NP_OUT * 32) + 32 * tp + 4 * g;
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(ws), w1 = *reinterpret_cast<const f32x4*>(ws + 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        heads.sigma = __builtin_fmaf(w0[j], v[j], heads.sigma);
+        heads.sigma = __builtin_fmaf(w1[j], v[4 + j], heads.sigma);
+      }
+    }
+    if (EPI == EPI_RGB) {
+      const float* wr = net.aux + (net.n_layers + 3) * (NP_OUT * 64) + 32 * tp + 4 * g;  // D = 64 NP_OUT here
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr + c * (NP_OUT * 32));
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(wr + c * (NP_OUT * 32) + 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          heads.rgb[c] = __builtin_fmaf(w0[j], v[j], heads.rgb[c]);
+          heads.rgb[c] = __builtin_fmaf(w1[j], v[4 + j], heads.rgb[c]);
+        }
+      }
+    }
+    // The empty asm statements pin each pair's results here.  Without them LLVM sinks the pure conversion
+    // arithmetic to its first use (the next layer): all accumulator pairs of the layer then stay alive until
+    // its end (64 more registers) and the conversions run in one block after the last MFMA.
+    if (EPI == EPI_LAST_FULL || EPI == EPI_LAST_DENS) asm volatile("" : "+v"(heads.sigma));
+    if (EPI == EPI_RGB) asm volatile("" : "+v"(heads.rgb[0]), "+v"(heads.rgb[1]), "+v"(heads.rgb[2]));
+    if (EPI == EPI_RELU_CVT || EPI == EPI_CVT || EPI == EPI_LAST_FULL) {
+      Frag& o = out[tp < NOUT ? tp : 0];
+#ifdef FSN_ABL_NOCVT  // timing experiment: skip the fp32 -> hi/lo split
+      asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+      o = out[0];
+#else
+      split_store<F16, X3>(v, o);
+      if constexpr (F16) range_track<EPI == EPI_CVT || EPI == EPI_NONE>(heads.fmax, o.hi);
+#endif
+      if (X3) asm volatile("" : "+v"(o.hi), "+v"(o.lo));
+      else asm volatile("" : "+v"(o.hi));
+    }
+}
+
+// ---------------------------------------------------------------- hand-scheduled k-loop blocks (kloop_gen.hpp)
+// FSN_KLOOP_ASM (defined by the translation unit) selects them for the x3 / x2 modes of 256-wide networks: one
+// inline-asm block per output pair with the A operands two units ahead of their MFMAs (three register sets in
+// rotation), counted waits, and the weight-phase openings inside the stream.  tools/gen_kloop.py documents the
+// operand contract.  The blocks exist for (units per pair, offset of the pair's first unit inside a phase):
+// 16/0 (256->256), 20/0,4 (skip layer), 18/0,2,4,6 (branch), 4/0,4 (first layer).
+#ifdef FSN_KLOOP_ASM
+constexpr bool kKloopAsm = true;
+#else
+constexpr bool kKloopAsm = false;
+#endif
+
+template <int N, class F, int... I>
+__device__ __forceinline__ void static_for_impl(F& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
+}
+
+#define FSN_KLOOP_OUTS_X3                                                                                      \
+  [c0] "=&v"(c0), [c1] "=&v"(c1), [s0h] "+v"(s0.hi), [s0l] "+v"(s0.lo), [s1h] "+v"(s1.hi), [s1l] "+v"(s1.lo), \
+      [s2h] "+v"(s2.hi), [s2l] "+v"(s2.lo), [keep] "=&s"(keep)
+#define FSN_KLOOP_OUTS_X2 \
+  [c0] "=&v"(c0), [c1] "=&v"(c1), [s0h] "+v"(s0.hi), [s1h] "+v"(s1.hi), [s2h] "+v"(s2.hi), [keep] "=&s"(keep)
+#define FSN_B(k) bsel<k, KS_ACT, KS_ENC>(act, enc)
+#define FSN_KLOOP_INS                                                                                               \
+  [z0] "v"(z0), [z1] "v"(z1), [b0h] "v"(FSN_B(0).hi), [b0l] "v"(FSN_B(0).lo), [b1h] "v"(FSN_B(1).hi),              \
+      [b1l] "v"(FSN_B(1).lo), [b2h] "v"(FSN_B(2).hi), [b2l] "v"(FSN_B(2).lo), [b3h] "v"(FSN_B(3).hi),              \
+      [b3l] "v"(FSN_B(3).lo), [b4h] "v"(FSN_B(4).hi), [b4l] "v"(FSN_B(4).lo), [b5h] "v"(FSN_B(5).hi),              \
+      [b5l] "v"(FSN_B(5).lo), [b6h] "v"(FSN_B(6).hi), [b6l] "v"(FSN_B(6).lo), [b7h] "v"(FSN_B(7).hi),              \
+      [b7l] "v"(FSN_B(7).lo), [b8h] "v"(FSN_B(8).hi), [b8l] "v"(FSN_B(8).lo), [b9h] "v"(FSN_B(9).hi),              \
+      [b9l] "v"(FSN_B(9).lo), [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [voff] "v"(voff),    \
+      [mv0] "s"(mv[0]), [gb0] "s"(gb[0]), [mv1] "s"(mv[1]), [gb1] "s"(gb[1]), [mv2] "s"(mv[2]), [gb2] "s"(gb[2])
+#define FSN_KLOOP_CASE(MODE, NU_, OFF_)                                                                          \
+  if constexpr (NU == NU_ && OFF == OFF_) {                                                                      \
+    constexpr int EV = FSN_KLOOP_##MODE##_##NU_##_##OFF_##_EVENTS, NP = FSN_KLOOP_##MODE##_##NU_##_##OFF_##_PHASES; \
+    kloop_plan<EV, NP>(st, a, mv, gb);                                                                           \
+    if constexpr (F16)                                                                                           \
+      asm volatile(FSN_KLOOP_##MODE##_##NU_##_##OFF_("v_mfma_f32_16x16x32_f16")                                \
+                   : FSN_KLOOP_OUTS_##MODE : FSN_KLOOP_INS : "memory");                                          \
+    else                                                                                                         \
+      asm volatile(FSN_KLOOP_##MODE##_##NU_##_##OFF_("v_mfma_f32_16x16x32_bf16")                               \
+                   : FSN_KLOOP_OUTS_##MODE : FSN_KLOOP_INS : "memory");                                          \
+    st.opened(EV);                                                                                               \
+  }
+
+// phase addresses and stage descriptors of a block with EV openings touching NP phases; unused slots repeat slot 0
+template <int EV, int NP>
+__device__ __forceinline__ void kloop_plan(WStream& st, uint32_t (&a)[4], uint32_t (&mv)[3], uint64_t (&gb)[3]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) a[k] = st.phase_lds(k < NP ? k : 0);
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    if (e < EV) st.next_stage(mv[e], gb[e]);
+    else { mv[e] = mv[0]; gb[e] = gb[0]; }
+  }
+}
+
+// B operand of k-step K: activations first, then the encoding; K past the last k-step repeats the last one (the
+// block's text does not reference it)
+template <int K, int KS_ACT, int KS_ENC, int NACT, int NENC>
+__device__ __forceinline__ const Frag& bsel(const Frag (&act)[NACT], const Frag (&enc)[NENC]) {
+  constexpr int kk = K < KS_ACT + KS_ENC ? K : KS_ACT + KS_ENC - 1;
+  if constexpr (kk < KS_ACT) return act[kk];
+  else return enc[kk - KS_ACT];
+}
+
+// One output pair: NU = 2 x k-steps units starting OFF units into the current phase; z0/z1: initial accumulators;
+// s0,s1: A sets holding units 0,1 on entry; on exit units NU, NU+1 sit in sets (NU % 3), ((NU+1) % 3) of (s0,s1,s2).
+template <bool F16, bool TWO, int KS_ACT, int KS_ENC, int OFF, int NACT, int NENC>
+__device__ __forceinline__ void kloop_block(WStream& st, const Frag (&act)[NACT], const Frag (&enc)[NENC],
+                                            const f32x4& z0, const f32x4& z1, f32x4& c0, f32x4& c1, AFrag& s0,
+                                            AFrag& s1, AFrag& s2) {
+  constexpr int NU = 2 * (KS_ACT + KS_ENC);
+  uint32_t a[4], mv[3], keep;
+  uint64_t gb[3];
+  const uint32_t voff = (threadIdx.x >> 6) * (kGldsPerWave * 1024) + (threadIdx.x & 63) * 16;
+  if constexpr (!TWO) {
+    FSN_KLOOP_CASE(X3, 16, 0)
+    FSN_KLOOP_CASE(X3, 20, 0)
+    FSN_KLOOP_CASE(X3, 20, 4)
+    FSN_KLOOP_CASE(X3, 18, 0)
+    FSN_KLOOP_CASE(X3, 18, 2)
+    FSN_KLOOP_CASE(X3, 18, 4)
+    FSN_KLOOP_CASE(X3, 18, 6)
+    FSN_KLOOP_CASE(X3, 4, 0)
+    FSN_KLOOP_CASE(X3, 4, 4)
+  } else {
+    FSN_KLOOP_CASE(X2, 16, 0)
+    FSN_KLOOP_CASE(X2, 20, 0)
+    FSN_KLOOP_CASE(X2, 20, 4)
+    FSN_KLOOP_CASE(X2, 18, 0)
+    FSN_KLOOP_CASE(X2, 18, 2)
+    FSN_KLOOP_CASE(X2, 18, 4)
+    FSN_KLOOP_CASE(X2, 18, 6)
+    FSN_KLOOP_CASE(X2, 4, 0)
+    FSN_KLOOP_CASE(X2, 4, 4)
+  }
+  (void)keep;
+}
+
 
 // NP_OUT output pairs (32 features = two 16-row tiles); KS_ACT k-steps (of 32) from `act`, KS_ENC
 // from `enc`; units are consumed in (pair, k-step, half) order starting phase-aligned.  Epilogue
@@ -384,6 +624,39 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
   constexpr int TOTAL = 2 * NP_OUT * KS;
   static_assert(KS_ACT <= NACT && KS_ENC <= NENC, "operand arrays too small");
   const float* bias = net.aux + aux_bias;
+  if constexpr (kKloopAsm && X3 && (KS == 8 || KS == 10 || KS == 9 || KS == 2) &&
+                (KS_ACT == 8 || (KS_ACT == 0 && NP_OUT == 8))) {
+    // hand-scheduled path (256-wide networks): ring.cur[0], cur[1] hold this GEMM's units 0 and 1 on entry and the
+    // next GEMM's on exit; inside, the three A sets rotate by NU units per pair (compile-time indices)
+    constexpr int NU = 2 * KS;
+    static_assert(TOTAL % UPP == 0, "a GEMM of the hand-scheduled path ends on a phase boundary");
+    static_for<NP_OUT>([&](auto TP) __attribute__((always_inline)) {
+      constexpr int tp = decltype(TP)::value;
+      constexpr int R0 = (tp * NU) % 3, OFF = (tp * NU) % UPP;
+      f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (!HK::kZeroInit) {
+        z0 = *reinterpret_cast<const f32x4*>(bias + 32 * tp + 4 * g);
+        z1 = *reinterpret_cast<const f32x4*>(bias + 32 * tp + 16 + 4 * g);
+      }
+      hk.pre(tp);
+#if defined(FSN_PRIO) && FSN_PRIO == 4
+      if (__builtin_amdgcn_readfirstlane(threadIdx.x) & 256) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
+      f32x4 acc0, acc1;
+      kloop_block<F16, PREC == 6, KS_ACT, KS_ENC, OFF>(st, act, enc, z0, z1, acc0, acc1, ring.cur[R0],
+                                                       ring.cur[(R0 + 1) % 3], ring.cur[(R0 + 2) % 3]);
+      pair_epilogue<PREC, NP_OUT, EPI>(net, tp, acc0, acc1, out, heads, g, hk);
+    });
+    constexpr int RE = TOTAL % 3;  // sets holding the next GEMM's units 0, 1
+    if constexpr (RE == 1) {
+      const AFrag t = ring.cur[0];
+      ring.cur[0] = ring.cur[1]; ring.cur[1] = ring.cur[2]; ring.cur[2] = t;
+    } else if constexpr (RE == 2) {
+      const AFrag t = ring.cur[1];
+      ring.cur[1] = ring.cur[0]; ring.cur[0] = ring.cur[2]; ring.cur[2] = t;
+    }
+    return;
+  }
 #pragma unroll
   for (int tp = 0; tp < NP_OUT; ++tp) {
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -397,7 +670,7 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
 #elif defined(FSN_PRIO) && FSN_PRIO == 2
     __builtin_amdgcn_s_setprio(0);
 #elif defined(FSN_PRIO) && FSN_PRIO == 4
-    if (threadIdx.x & 256) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x) & 256) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
 #endif
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -457,60 +730,7 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
         }
       }
     }
-    // ---- epilogue of pair tp
-#if defined(FSN_PRIO) && FSN_PRIO == 1
-    __builtin_amdgcn_s_setprio(0);
-#elif defined(FSN_PRIO) && FSN_PRIO == 2
-    __builtin_amdgcn_s_setprio(1);
-#elif defined(FSN_PRIO) && FSN_PRIO == 4
-    __builtin_amdgcn_s_setprio(2);
-#endif
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { v[j] = acc0[j]; v[4 + j] = acc1[j]; }
-    if (EPI != EPI_CVT && EPI != EPI_NONE) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = relu_f32(v[j]);
-    }
-    hk.post(tp, v);
-    if (EPI == EPI_LAST_FULL || EPI == EPI_LAST_DENS) {
-      const float* ws = net.aux + (net.n_layers + 2) * (NP_OUT * 32) + 32 * tp + 4 * g;
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(ws), w1 = *reinterpret_cast<const f32x4*>(ws + 16);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        heads.sigma = __builtin_fmaf(w0[j], v[j], heads.sigma);
-        heads.sigma = __builtin_fmaf(w1[j], v[4 + j], heads.sigma);
-      }
-    }
-    if (EPI == EPI_RGB) {
-      const float* wr = net.aux + (net.n_layers + 3) * (NP_OUT * 64) + 32 * tp + 4 * g;  // D = 64 NP_OUT here
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr + c * (NP_OUT * 32));
-        const f32x4 w1 = *reinterpret_cast<const f32x4*>(wr + c * (NP_OUT * 32) + 16);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          heads.rgb[c] = __builtin_fmaf(w0[j], v[j], heads.rgb[c]);
-          heads.rgb[c] = __builtin_fmaf(w1[j], v[4 + j], heads.rgb[c]);
-        }
-      }
-    }
-    // The empty asm statements pin each pair's results here.  Without them LLVM sinks the pure conversion
-    // arithmetic to its first use (the next layer): all accumulator pairs of the layer then stay alive until
-    // its end (64 more registers) and the conversions run in one block after the last MFMA.
-    if (EPI == EPI_LAST_FULL || EPI == EPI_LAST_DENS) asm volatile("" : "+v"(heads.sigma));
-    if (EPI == EPI_RGB) asm volatile("" : "+v"(heads.rgb[0]), "+v"(heads.rgb[1]), "+v"(heads.rgb[2]));
-    if (EPI == EPI_RELU_CVT || EPI == EPI_CVT || EPI == EPI_LAST_FULL) {
-      Frag& o = out[tp < NOUT ? tp : 0];
-#ifdef FSN_ABL_NOCVT  // timing experiment: skip the fp32 -> hi/lo split
-      asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
-      o = act[0];
-#else
-      split_store<F16, X3>(v, o);
-#endif
-      if (X3) asm volatile("" : "+v"(o.hi), "+v"(o.lo));
-      else asm volatile("" : "+v"(o.hi));
-    }
+    pair_epilogue<PREC, NP_OUT, EPI>(net, tp, acc0, acc1, out, heads, g, hk);
   }
 }
 
@@ -523,9 +743,15 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
 }
 
 // A-operand pair primed for the very first GEMM of a kernel (after WStream::init opened phase 0)
-template <int PREC>
+template <int PREC, int NT = 0>
 __device__ __forceinline__ void prime_ring(const WStream& st, ARing& ring) {
   constexpr int UB = (PREC & 1) == 0 ? 2048 : 1024;
+  if (kKloopAsm && (PREC & 1) == 0 && NT == 8) {  // hand-scheduled x3 / x2 path: units 0 and 1 of the first GEMM
+    load_afrag<PREC>(st.n_base, ring.cur[0]);
+    load_afrag<PREC>(st.n_base + UB, ring.cur[1]);
+    ring.cur[2] = ring.cur[0];
+    return;
+  }
 #ifdef FSN_X3_PF1
   if ((PREC & 1) == 0) {
     load_afrag<PREC>(st.n_base, ring.cur[0]);
@@ -564,7 +790,7 @@ __device__ __forceinline__ void mlp_tile(WStream& st, const NetDev& net, const S
   const float* misc = net.aux + (L + 5) * D;
   Frag A[NA], B[NA];
   Frag none[1];
-  Heads heads{0.f, {0.f, 0.f, 0.f}};
+  Heads heads{0.f, {0.f, 0.f, 0.f}, 0u};
   {
     Frag pe[kKsPos];
     float px, py, pz;
@@ -628,6 +854,7 @@ __device__ __forceinline__ void mlp_tile(WStream& st, const NetDev& net, const S
       rgb[c] = 1.0f / (1.0f + expf(-z));  // sigmoid (models.py:135)
     }
   }
+  if constexpr (F16) range_report(net.status, heads.fmax);
 }
 
 template <int NT, int PREC, bool FULL, class Src>
@@ -655,6 +882,7 @@ __device__ __forceinline__ void load_net(const NetParams& p, const float* __rest
   net.skip_mask = p.skip_mask;
   net.n_freqs_pos = p.n_freqs_pos;
   net.n_freqs_dir = p.n_freqs_dir;
+  net.status = p.status;
 }
 
 }  // namespace fsn

@@ -141,7 +141,7 @@ FSN_HD float half_to_f32(uint16_t h, bool f16) { return f16 ? f16_to_f32(h) : bf
 // Fills `G` from the descriptor; returns 0 or an FSN_E_* code (message via set_error on host).
 inline int build_geom(const fsn_mlp_desc& d, int prec, NetGeom& G, const char** why) {
   *why = "";
-  if (prec < 0 || prec > 3) { *why = "unknown precision mode"; return FSN_E_INVALID; }
+  if (prec < 0 || (prec > 3 && prec != FSN_PREC_FP16X2)) { *why = "unknown precision mode"; return FSN_E_INVALID; }
   if (d.d_hidden != 256 && d.d_hidden != 128) { *why = "d_hidden must be 128 or 256"; return FSN_E_UNSUPPORTED; }
   if (d.n_layers < 2 || d.n_layers > kMaxLayers) { *why = "n_layers must be in [2,16]"; return FSN_E_UNSUPPORTED; }
   if (d.n_freqs_pos < 0 || d.n_freqs_pos > 10) { *why = "n_freqs (position) must be <= 10"; return FSN_E_UNSUPPORTED; }

@@ -11,6 +11,8 @@
 // waves 0..3 (waves w and w+4 share a SIMD): +1.3 % and a further +0.5 % in this kernel (A/B on MI355X; the standalone
 // MLP kernel loses 1.6 % with priority changes and leaves them off)
 #define FSN_PRIO 4
+// hand-scheduled k-loop of the x3 modes (kloop_gen.hpp): A operands two units ahead, counted waits
+#define FSN_KLOOP_ASM
 #include "mlp_dev.hpp"
 #include "ray_dev.hpp"
 
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
           k.netF.blob + k.netF.stream_off, (uint32_t)k.netF.nph_full, (uint32_t)k.nsubF);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   ARing ring;
-  prime_ring<PREC>(st, ring);
+  prime_ring<PREC, NT>(st, ring);
   for (int64_t grp = blockIdx.x; grp < (GRP_R + GRP_G - 1) / GRP_G; grp += gridDim.x) {
     const int64_t r0 = grp * GRP_G;
     // ---- rays and coarse interval edges into LDS
@@ -187,13 +189,14 @@ static int launch_render(const RenderKArgs& k, int cus, hipStream_t s) {
   return FSN_OK;
 }
 
-static NetParams net_params(const fsn_mlp_desc& d, const NetGeom& G, const void* blob) {
+static NetParams net_params(const fsn_mlp_desc& d, const NetGeom& G, const void* blob, uint32_t* status) {
   NetParams p;
   p.blob = static_cast<const char*>(blob);
   p.aux_off = (int32_t)G.aux_off; p.aux_floats = G.aux_floats; p.stream_off = (int32_t)G.stream_off;
   p.nph_density = G.nph_density; p.nph_full = G.nph_full;
   p.n_layers = d.n_layers; p.skip_mask = d.skip_mask;
   p.n_freqs_pos = d.n_freqs_pos; p.n_freqs_dir = d.n_freqs_dir;
+  p.status = status;
   return p;
 }
 
@@ -226,8 +229,8 @@ extern "C" int fsn_render_rays_fused(const fsn_mlp_desc* desc, int prec, const v
   }
   FSN_REQUIRE(G.aux_floats <= kAuxCapFloats, FSN_E_UNSUPPORTED, "fsn_render_rays_fused: network too deep for LDS");
   RenderKArgs k;
-  k.netF = net_params(*desc, G, blob_fine);
-  k.netC = net_params(*desc, G, a.n_imp > 0 ? blob_coarse : blob_fine);
+  k.netF = net_params(*desc, G, blob_fine, a.status);
+  k.netC = net_params(*desc, G, a.n_imp > 0 ? blob_coarse : blob_fine, a.status);
   k.a = a;
   int g = 128 / a.S;
   if (g < 1) g = 1;
@@ -241,6 +244,7 @@ extern "C" int fsn_render_rays_fused(const fsn_mlp_desc* desc, int prec, const v
   const int cus = fsn_device_cus();
   if (cus <= 0) return FSN_E_HIP;
   hipStream_t s = as_stream(stream);
+  if (prec == FSN_PREC_FP16X2) return desc->d_hidden == 256 ? launch_render<8, 6>(k, cus, s) : launch_render<4, 6>(k, cus, s);
   const int key = (desc->d_hidden == 256 ? 4 : 0) + prec;
   switch (key) {
     case 0: return launch_render<4, 0>(k, cus, s);

@@ -300,7 +300,7 @@ extern "C" int64_t fsn_nerf_train_workspace_floats(const fsn_mlp_desc* desc, int
 
 extern "C" int fsn_nerf_train_fwd(const fsn_mlp_desc* desc, int prec, const float* const* W, const float* const* b,
                                   const float* x, const float* dirs, const float* pos_mask, const float* dir_mask,
-                                  int64_t n, float* ws, float* out, fsn_stream_t stream) {
+                                  int64_t n, float* ws, float* out, uint32_t* status, fsn_stream_t stream) {
   int rc = check_desc(desc);
   if (rc != FSN_OK) return rc;
   FSN_REQUIRE(prec >= 0 && prec <= FSN_PREC_FP32, FSN_E_INVALID, "fsn_nerf_train_fwd: unknown precision");
@@ -308,7 +308,7 @@ extern "C" int fsn_nerf_train_fwd(const fsn_mlp_desc* desc, int prec, const floa
   FSN_REQUIRE(W && b && x && dirs && ws && out, FSN_E_INVALID, "fsn_nerf_train_fwd: null pointer");
   FSN_REQUIRE(n < (1ll << 31), FSN_E_UNSUPPORTED, "fsn_nerf_train_fwd: n too large for one call");
   hipStream_t s = as_stream(stream);
-  if (prec != FSN_PREC_FP32) return fused_train_fwd(desc, prec, W, b, x, dirs, pos_mask, dir_mask, n, ws, out, s);
+  if (prec != FSN_PREC_FP32) return fused_train_fwd(desc, prec, W, b, x, dirs, pos_mask, dir_mask, n, ws, out, status, s);
   RocBlas* rb;
   rc = rb_get(s, &rb);
   if (rc != FSN_OK) return rc;
@@ -364,7 +364,7 @@ extern "C" int fsn_nerf_train_fwd(const fsn_mlp_desc* desc, int prec, const floa
 
 extern "C" int fsn_nerf_train_bwd(const fsn_mlp_desc* desc, int prec, const float* const* W, int64_t n, float* ws,
                                   const float* out, const float* d_out, const float* grad_scale, float* const* dW,
-                                  float* const* db, fsn_stream_t stream) {
+                                  float* const* db, uint32_t* status, fsn_stream_t stream) {
   int rc = check_desc(desc);
   if (rc != FSN_OK) return rc;
   FSN_REQUIRE(prec >= 0 && prec <= FSN_PREC_FP32, FSN_E_INVALID, "fsn_nerf_train_bwd: unknown precision");
@@ -372,7 +372,7 @@ extern "C" int fsn_nerf_train_bwd(const fsn_mlp_desc* desc, int prec, const floa
   FSN_REQUIRE(n > 0 && ws && out && d_out, FSN_E_INVALID, "fsn_nerf_train_bwd: needs the forward's workspace (n > 0)");
   FSN_REQUIRE(n < (1ll << 31), FSN_E_UNSUPPORTED, "fsn_nerf_train_bwd: n too large for one call");
   hipStream_t s = as_stream(stream);
-  if (prec != FSN_PREC_FP32) return fused_train_bwd(desc, prec, W, n, ws, out, d_out, grad_scale, dW, db, s);
+  if (prec != FSN_PREC_FP32) return fused_train_bwd(desc, prec, W, n, ws, out, d_out, grad_scale, dW, db, status, s);
   FSN_REQUIRE(!grad_scale, FSN_E_INVALID, "fsn_nerf_train_bwd: grad_scale applies to the 16-bit MFMA modes only");
   RocBlas* rb;
   rc = rb_get(s, &rb);

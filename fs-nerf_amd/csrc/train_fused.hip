@@ -317,7 +317,7 @@ __global__ __launch_bounds__(kThreads) void k_train_bwd(TrainBwdArgs a) {
   const float scale = a.scale ? a.scale[0] : 1.0f;
   ARing ring;
   prime_ring<PREC>(st, ring);
-  Heads heads{0.f, {0.f, 0.f, 0.f}};
+  Heads heads{0.f, {0.f, 0.f, 0.f}, 0u};
   Frag none[1];
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t s = tile * kTC + col;
@@ -394,6 +394,7 @@ __global__ __launch_bounds__(kThreads) void k_train_bwd(TrainBwdArgs a) {
         gemm_layer<PREC, NT, NT, 0, EPI_CVT>(st, net, 0, A, none, B, heads, ring, g, hk);
       }
     }
+    if constexpr (F16) range_report(net.status, heads.fmax);  // a scaled gradient left the fp16 range
   }
   st.drain();
 }
@@ -697,13 +698,14 @@ __global__ void k_heads_reduce(HeadsRdArgs a) {
 }
 
 // ------------------------------------------------------------------ host side
-static NetParams net_params(const fsn_mlp_desc& d, const NetGeom& G, const void* blob) {
+static NetParams net_params(const fsn_mlp_desc& d, const NetGeom& G, const void* blob, uint32_t* status) {
   NetParams p;
   p.blob = static_cast<const char*>(blob);
   p.aux_off = (int32_t)G.aux_off; p.aux_floats = G.aux_floats; p.stream_off = (int32_t)G.stream_off;
   p.nph_density = G.nph_density; p.nph_full = G.nph_full;
   p.n_layers = d.n_layers; p.skip_mask = d.skip_mask;
   p.n_freqs_pos = d.n_freqs_pos; p.n_freqs_dir = d.n_freqs_dir;
+  p.status = status;
   return p;
 }
 
@@ -743,7 +745,7 @@ static int launch_wgrad(int prec, const WgArgs& a, int njobs, hipStream_t s) {
 
 int fused_train_fwd(const fsn_mlp_desc* d, int prec, const float* const* W, const float* const* b, const float* x,
                     const float* dirs, const float* pos_mask, const float* dir_mask, int64_t n, float* ws, float* out,
-                    hipStream_t s) {
+                    uint32_t* status, hipStream_t s) {
   FusedLayout F;
   const char* why;
   int rc = make_fused_layout(*d, prec, n, F, &why);
@@ -756,7 +758,7 @@ int fused_train_fwd(const fsn_mlp_desc* d, int prec, const float* const* W, cons
   if (rc != FSN_OK) return rc;
   const int cus = fsn_device_cus();
   if (cus <= 0) return FSN_E_HIP;
-  TrainFwdArgs a{net_params(*d, G, blob), x, dirs, pos_mask, dir_mask, n, out, ws, F.h, F.h_stride, F.bo, F.pe, F.de,
+  TrainFwdArgs a{net_params(*d, G, blob, status), x, dirs, pos_mask, dir_mask, n, out, ws, F.h, F.h_stride, F.bo, F.pe, F.de,
                  F.mask, F.mask_stride, F.D};
   const unsigned grid = (unsigned)(F.T < cus ? F.T : cus);
   const int key = (F.D == 256 ? 4 : 0) + prec;
@@ -773,7 +775,8 @@ int fused_train_fwd(const fsn_mlp_desc* d, int prec, const float* const* W, cons
 }
 
 int fused_train_bwd(const fsn_mlp_desc* d, int prec, const float* const* W, int64_t n, float* ws, const float* out,
-                    const float* d_out, const float* grad_scale_dev, float* const* dW, float* const* db, hipStream_t s) {
+                    const float* d_out, const float* grad_scale_dev, float* const* dW, float* const* db,
+                    uint32_t* status, hipStream_t s) {
   FusedLayout F;
   const char* why;
   int rc = make_fused_layout(*d, prec, n, F, &why);
@@ -801,7 +804,7 @@ int fused_train_bwd(const fsn_mlp_desc* d, int prec, const float* const* W, int6
   }
   // ---- dgrad chain
   {
-    TrainBwdArgs a{net_params(*d, G, ws + F.blob_f), reinterpret_cast<const char*>(ws + F.blob_b), F.nph_bwd, n, out, d_out,
+    TrainBwdArgs a{net_params(*d, G, ws + F.blob_f, status), reinterpret_cast<const char*>(ws + F.blob_b), F.nph_bwd, n, out, d_out,
                    grad_scale_dev, ws, F.h, F.h_stride, F.bo, F.dhead, F.dbo, F.dp, F.mask, F.mask_stride};
     const unsigned grid = (unsigned)(F.T < cus ? F.T : cus);
     const int key = (D == 256 ? 4 : 0) + prec;

@@ -175,6 +175,31 @@ def composite_packed(sigmas: Tensor, rgbs: Tensor, t_starts: Tensor, t_ends: Ten
 # ------------------------------------------------------------------ MLP
 SD_ORDER_TAIL = ("sigma", "connection", "branch", "rgb")
 
+# Range guard of the fp16 modes (include/fsnerf_hip.h, FSN_STATUS_FP16_RANGE): one sticky device word per GPU that
+# every MLP launch of this process reports into.
+_status_words: Dict[torch.device, Tensor] = {}
+
+
+def status_word(device) -> Tensor:
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    w = _status_words.get(device)
+    if w is None:
+        w = _status_words[device] = torch.zeros(1, dtype=torch.int32, device=device)
+    return w
+
+
+def range_ok(device) -> bool:
+    """False when a launch since the last call reported an activation (or scaled gradient) outside the fp16 range;
+    the word is cleared.  Reads 4 bytes back: one host sync."""
+    w = status_word(device)
+    bad = bool(int(w.item()) & L.FSN_STATUS_FP16_RANGE)
+    if bad:
+        w.zero_()
+    return not bad
+
+
 
 def make_desc(n_layers: int, d_hidden: int, skip: Sequence[int], freqs_pos: Sequence[float],
               freqs_dir: Sequence[float]) -> L.MlpDesc:
@@ -238,7 +263,7 @@ def mlp_fwd(pm: PackedMLP, x: Tensor, dirs: Optional[Tensor] = None, pos_mask: O
     out = torch.empty(*lead, 4 if d is not None else 1, device=x.device, dtype=torch.float32)
     with torch.cuda.device(x.device):
         L.check(L.lib().fsn_mlp_fwd(C.byref(pm.desc), pm.prec, _p(pm.blob), _p(x), _p(d), _p(pmk), _p(dmk), n,
-                                    _p(out), _stream()), "fsn_mlp_fwd")
+                                    _p(out), _p(status_word(x.device)), _stream()), "fsn_mlp_fwd")
     return out
 
 
@@ -288,6 +313,9 @@ def render_fused(pm_coarse: Optional[PackedMLP], pm_fine: PackedMLP, rays_o: Ten
             a.weights_coarse = ex["weights_coarse"].data_ptr()
     if NI > 0 and pm_coarse is None:
         pm_coarse = pm_fine
+    if pm_coarse is not None and pm_coarse.prec != pm_fine.prec:
+        raise ValueError("render_fused: the coarse and the fine network must be packed in the same precision mode")
+    a.status = status_word(dev).data_ptr()
     with torch.cuda.device(dev):
         L.check(L.lib().fsn_render_rays_fused(C.byref(pm_fine.desc), pm_fine.prec,
                                               _p(pm_coarse.blob) if pm_coarse is not None else None,
@@ -368,7 +396,8 @@ def nerf_train_fwd(desc: L.MlpDesc, prec: int, weights: Sequence[Tensor], biases
         pm = None if pos_mask is None else _f32(pos_mask, "pos_mask")
         dm = None if dir_mask is None else _f32(dir_mask, "dir_mask")
         L.check(L.lib().fsn_nerf_train_fwd(C.byref(desc), prec, _ptr_array(ws_), _ptr_array(bs_), _p(x), _p(d), _p(pm),
-                                           _p(dm), n, _p(work), _p(out), _stream()), "fsn_nerf_train_fwd")
+                                           _p(dm), n, _p(work), _p(out), _p(status_word(x.device)), _stream()),
+                "fsn_nerf_train_fwd")
     return out, work
 
 
@@ -393,7 +422,8 @@ def nerf_train_bwd(desc: L.MlpDesc, prec: int, weights: Sequence[Tensor], work: 
     scale = grad_scale_for(d_out) if prec in (L.FSN_PREC_FP16X3, L.FSN_PREC_FP16) else None
     with torch.cuda.device(work.device):
         L.check(L.lib().fsn_nerf_train_bwd(C.byref(desc), prec, _ptr_array(ws_), n, _p(work), _p(out), _p(d_out),
-                                           _p(scale), _ptr_array(dW), _ptr_array(db), _stream()), "fsn_nerf_train_bwd")
+                                           _p(scale), _ptr_array(dW), _ptr_array(db), _p(status_word(work.device)),
+                                           _stream()), "fsn_nerf_train_bwd")
     return dW, db
 
 

@@ -145,10 +145,20 @@ def render_rays(rays_o: Tensor, rays_d: Tensor, estimator, model: nn.Module, tra
         near, far = estimator.bounds()
         pm = fine._mask(fine.pos_mask, rays_o.device)
         dm = fine._mask(fine.dir_mask, rays_o.device)
-        rgb, opacity, depth, ex = ops.render_fused(
-            model.packed() if estimator.n_importance > 0 else None, fine.packed(), rays_o, rays_d,
-            near=near, far=far, n_samples=estimator.n_samples, n_importance=estimator.n_importance,
-            u=u, u_fine=u_fine, bkgd=(bk, bk, bk), pos_mask=pm, dir_mask=dm, want_extras=want_extras)
+        def launch():
+            return ops.render_fused(
+                model.packed() if estimator.n_importance > 0 else None, fine.packed(), rays_o, rays_d,
+                near=near, far=far, n_samples=estimator.n_samples, n_importance=estimator.n_importance,
+                u=u, u_fine=u_fine, bkgd=(bk, bk, bk), pos_mask=pm, dir_mask=dm, want_extras=want_extras)
+
+        rgb, opacity, depth, ex = launch()
+        nets = [m for m in {id(model): model, id(fine): fine}.values()]
+        if any(m.range_check and m.fp16_family(m.PRECISIONS[m.precision]) for m in nets) and \
+                not ops.range_ok(rays_o.device):
+            for m in nets:  # the coarse and the fine pass run in one precision mode
+                if m.fp16_family(m.PRECISIONS[m.precision]):
+                    m.fall_back("render_rays")
+            rgb, opacity, depth, ex = launch()
         if not want_extras:  # frame rendering: only rgb / depth are consumed (rendering.py:169-171)
             return (rgb, opacity, depth, ex), None, None
         edges = ex["edges"]

@@ -39,6 +39,15 @@ typedef void* fsn_stream_t; /* hipStream_t */
 #define FSN_PREC_FP16X3 2 /* split-fp16 (hi+lo) x 3 MFMA passes: fp32-grade accuracy; |activation| must stay
                              below 65504 (fp16 range) - the default "parity" mode */
 #define FSN_PREC_FP16 3   /* single fp16 MFMA pass */
+#define FSN_PREC_FP16X2 6 /* two fp16 MFMA passes: activations high+low parts, weights' high part only (the x3 blob
+                             layout; inference only).  Measured accuracy in DESIGN.md - not the parity mode */
+
+/* Range guard of the fp16 modes.  Entry points that evaluate the MLP take `status`: a DEVICE pointer to one
+ * uint32_t owned by the caller (or NULL = no report).  A kernel sets bit 0 (atomic OR, never clears) when a hidden
+ * activation - or, in the training backward, a scaled gradient - reached fp16 infinity, i.e. left the range in
+ * which FSN_PREC_FP16X3 / _FP16 / _FP16X2 are valid; the results of that launch are then not to be used (re-run in
+ * FSN_PREC_BF16X3, which has the range of float32).  The bf16 modes never set it. */
+#define FSN_STATUS_FP16_RANGE 1u
 
 int fsn_version(void);
 const char* fsn_last_error(void);
@@ -123,7 +132,7 @@ int fsn_mlp_pack_host(const fsn_mlp_desc* desc, int prec, const float* const* we
  * pos_mask [3*(1+2*n_freqs_pos)] / dir_mask [3*(1+2*n_freqs_dir)] device pointers or NULL. */
 int fsn_mlp_fwd(const fsn_mlp_desc* desc, int prec, const void* blob, const float* x,
                 const float* dirs, const float* pos_mask, const float* dir_mask, int64_t n,
-                float* out, fsn_stream_t stream);
+                float* out, uint32_t* status, fsn_stream_t stream);
 
 /* ---- a6: render_rays(rays_o, rays_d, estimator, model, ...)   src/render/rendering.py:25-107
  * The whole path fused in one launch for the fixed-count sampler: stratified edges ->
@@ -156,6 +165,7 @@ typedef struct fsn_render_args {
   float* rgbs;
   float* edges_out;
   float* weights_coarse;
+  uint32_t* status; /* range guard of the fp16 modes (above), or NULL */
 } fsn_render_args;
 
 int fsn_render_rays_fused(const fsn_mlp_desc* desc, int prec, const void* blob_coarse,
@@ -194,10 +204,10 @@ int fsn_occlusion_reg_bwd(const float* t_vals, int64_t N, const float* ray_sums,
 int64_t fsn_nerf_train_workspace_floats(const fsn_mlp_desc* desc, int prec, int64_t n);
 int fsn_nerf_train_fwd(const fsn_mlp_desc* desc, int prec, const float* const* weights, const float* const* biases,
                        const float* x, const float* dirs, const float* pos_mask, const float* dir_mask,
-                       int64_t n, float* workspace, float* out, fsn_stream_t stream);
+                       int64_t n, float* workspace, float* out, uint32_t* status, fsn_stream_t stream);
 int fsn_nerf_train_bwd(const fsn_mlp_desc* desc, int prec, const float* const* weights, int64_t n, float* workspace,
                        const float* out, const float* d_out, const float* grad_scale, float* const* d_weights,
-                       float* const* d_biases, fsn_stream_t stream);
+                       float* const* d_biases, uint32_t* status, fsn_stream_t stream);
 /* backward of fsn_composite_packed_fwd with respect to sigmas and rgbs, given dL/dcolors [R,3] and
  * (optional) dL/dopacity [R]; dL/ddepth is not propagated. */
 int fsn_composite_packed_bwd(const float* sigmas, const float* rgbs, const float* t_starts, const float* t_ends,
