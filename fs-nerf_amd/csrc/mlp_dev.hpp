@@ -17,7 +17,10 @@
 #pragma once
 #include "common.hpp"
 #include "mlp_layout.hpp"
-#include "kloop_gen.hpp"
+#ifndef FSN_KLOOP_HEADER
+#define FSN_KLOOP_HEADER "kloop_gen.hpp"
+#endif
+#include FSN_KLOOP_HEADER
 
 #include <type_traits>
 #include <utility>
@@ -29,7 +32,18 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(8))) short s16x8;  // 8 raw 16-bit elements (bf16 or fp16 bits)
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-constexpr int kNSlot = 4;            // LDS ring slots (phases)
+#ifndef FSN_NSLOT
+#define FSN_NSLOT 4
+#endif
+#ifndef FSN_LAG
+#define FSN_LAG 0
+#endif
+constexpr int kNSlot = FSN_NSLOT;     // LDS ring slots (phases)
+// FSN_LAG = 1: waves 4..7 of the workgroup run the weight stream ONE PHASE behind waves 0..3 (their SIMD partners):
+// they execute the same instruction stream, delayed by one barrier event (WStream::pass_begin / pass_end), so that
+// one wave's pair epilogue / bookkeeping falls into the middle of its partner's MFMA k-loop instead of both waves
+// leaving the matrix pipe idle at the same time.  Needs two more ring slots (see kLook).
+constexpr int kLag = FSN_LAG;
 #ifndef FSN_LEAD
 #define FSN_LEAD 2
 #endif
@@ -39,7 +53,19 @@ constexpr int kNSlot = 4;            // LDS ring slots (phases)
 constexpr int kLead = FSN_LEAD;
 // phases staged ahead of the one being opened; with kLead > 0 the phase before the opened one is
 // still being read, so one more slot must stay untouched
-constexpr int kLook = kLead > 0 ? kNSlot - 2 : kNSlot - 1;
+// Ring safety (E_b = the b-th barrier event; a phase q is read by the leading waves between E_q and E_q+1 - plus
+// the two units after E_q+1 on the compiler-scheduled path - and by lagging waves one event later; the stage issued
+// at E_b overwrites the slot of phase b + kLook - kNSlot): kNSlot >= kLook + 2 + kLag.
+constexpr int kLook = kLead > 0 ? kNSlot - 2 - kLag : kNSlot - 1;
+// loads of this wave that may stay in flight when a phase is opened: the lagging waves' share of a phase must have
+// landed one event before they read it themselves (the leading waves read it then), hence "- kLag"
+constexpr int kOpenVmcnt = (kLook - 1 - kLag) * (kPhaseBytes / 1024 / 8);
+static_assert(kOpenVmcnt == 2, "the generated k-loop blocks wait with vmcnt(2)");
+__device__ __forceinline__ uint32_t slot_add(uint32_t s, uint32_t k) {  // (s + k) mod kNSlot, s < kNSlot, k <= kNSlot
+  if ((kNSlot & (kNSlot - 1)) == 0) return (s + k) & (kNSlot - 1);
+  const uint32_t t = s + k;
+  return t >= (uint32_t)kNSlot ? t - kNSlot : t;
+}
 constexpr int kWaves = 8;             // wavefronts per workgroup (two per SIMD)
 constexpr int kThreads = 64 * kWaves;
 constexpr int kGldsPerWave = kPhaseBytes / 1024 / kWaves;  // 1-KiB glds instructions per wave per phase
@@ -62,6 +88,9 @@ struct WStream {
   // stager state
   const char* s_ptr;
   uint32_t s_left, s_which, s_rep, s_slot;
+#ifdef FSN_STAMP  // diagnostic build: per-wave cycle totals (s_memtime) of the k-loop blocks / epilogues
+  uint64_t t_k = 0, t_e = 0, t_n = 0, t_ko = 0, t_eo = 0;
+#endif
   // consumer state
   uint32_t c_slot;
   const char* c_base;  // LDS address of the phase being computed (+ lane*16)
@@ -111,7 +140,7 @@ struct WStream {
         : "memory");
     static_assert(kGldsPerWave == 2, "stage() issues exactly 2 loads per wave");
     s_ptr += kPhaseBytes;
-    s_slot = (s_slot + 1) & (kNSlot - 1);
+    s_slot = slot_add(s_slot, 1);
     if (--s_left == 0) advance_pass_();
   }
   __device__ __forceinline__ void init(char* ring_, const char* pA, uint32_t nA, uint32_t rA, const char* pB,
@@ -133,16 +162,16 @@ struct WStream {
   __device__ __forceinline__ void open_next() {
 #ifdef FSN_ABL_NOSTREAM  // timing experiment: no waits, barriers or staging
     n_base = ring + c_slot * kPhaseBytes + (threadIdx.x & 63) * 16;
-    c_slot = (c_slot + 1) & (kNSlot - 1);
+    c_slot = slot_add(c_slot, 1);
     return;
 #endif
     if (kLead > 0)
-      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((kLook - 1) * kGldsPerWave) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kOpenVmcnt) : "memory");
     else
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((kLook - 1) * kGldsPerWave) : "memory");
     stage();
     n_base = ring + c_slot * kPhaseBytes + (threadIdx.x & 63) * 16;
-    c_slot = (c_slot + 1) & (kNSlot - 1);
+    c_slot = slot_add(c_slot, 1);
   }
   __device__ __forceinline__ void enter_phase() { c_base = n_base; }
   // ---- interface of the hand-scheduled k-loop blocks (kloop_gen.hpp), which carry the phase openings inside
@@ -157,16 +186,27 @@ struct WStream {
     const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(sp >> 32));
     gbase = ((uint64_t)hi << 32) | lo;
     s_ptr += kPhaseBytes;
-    s_slot = (s_slot + 1) & (kNSlot - 1);
+    s_slot = slot_add(s_slot, 1);
     if (--s_left == 0) advance_pass_();
   }
   __device__ __forceinline__ uint32_t phase_lds(uint32_t k) const {
-    return ring_lds + ((c_slot + kNSlot - 1 + k) & (kNSlot - 1)) * kPhaseBytes + (threadIdx.x & 63) * 16;
+    return ring_lds + slot_add(slot_add(c_slot, kNSlot - 1), k) * kPhaseBytes + (threadIdx.x & 63) * 16;
   }
   __device__ __forceinline__ void opened(uint32_t n) {
-    c_slot = (c_slot + n) & (kNSlot - 1);
-    n_base = ring + ((c_slot + kNSlot - 1) & (kNSlot - 1)) * kPhaseBytes + (threadIdx.x & 63) * 16;
+    c_slot = slot_add(c_slot, n);
+    n_base = ring + slot_add(c_slot, kNSlot - 1) * kPhaseBytes + (threadIdx.x & 63) * 16;
     c_base = n_base;
+  }
+  // ---- the one-phase lag between the two waves of a SIMD (kLag).  A "pass" is a run of MLP tiles between two
+  // workgroup barriers of the caller.  Waves 4..7 join one barrier event before their first unit (they then read
+  // phase p while waves 0..3 read phase p+1); waves 0..3 join one after their last so that every wave has taken
+  // part in the same number of events when the pass ends.  No staging, no waits: events only.
+  static __device__ __forceinline__ bool lagging() { return kLag && (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256); }
+  __device__ __forceinline__ void pass_begin() const {
+    if (kLag && lagging()) asm volatile("s_barrier" ::: "memory");
+  }
+  __device__ __forceinline__ void pass_end() const {
+    if (kLag && !lagging()) asm volatile("s_barrier" ::: "memory");
   }
   // before the workgroup exits (or touches the ring for anything else)
   __device__ __forceinline__ void drain() {
@@ -643,9 +683,28 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
       if (__builtin_amdgcn_readfirstlane(threadIdx.x) & 256) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
 #endif
       f32x4 acc0, acc1;
+#ifdef FSN_STAMP
+      const uint64_t ts0 = __builtin_amdgcn_s_memtime();
+#endif
       kloop_block<F16, PREC == 6, KS_ACT, KS_ENC, OFF>(st, act, enc, z0, z1, acc0, acc1, ring.cur[R0],
                                                        ring.cur[(R0 + 1) % 3], ring.cur[(R0 + 2) % 3]);
+#ifdef FSN_STAMP
+      const uint64_t ts1 = __builtin_amdgcn_s_memtime();
+#endif
       pair_epilogue<PREC, NP_OUT, EPI>(net, tp, acc0, acc1, out, heads, g, hk);
+#ifdef FSN_STAMP
+      {
+        const uint64_t ts2 = __builtin_amdgcn_s_memtime();
+        if (KS == 8) {  // the 256 -> 256 GEMMs
+          st.t_k += ts1 - ts0;
+          st.t_e += ts2 - ts1;
+          st.t_n += 1;
+        } else {  // first layer, skip layer, branch
+          st.t_ko += ts1 - ts0;
+          st.t_eo += ts2 - ts1;
+        }
+      }
+#endif
     });
     constexpr int RE = TOTAL % 3;  // sets holding the next GEMM's units 0, 1
     if constexpr (RE == 1) {

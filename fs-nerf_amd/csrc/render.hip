@@ -13,6 +13,15 @@
 #define FSN_PRIO 4
 // hand-scheduled k-loop of the x3 modes (kloop_gen.hpp): A operands two units ahead, counted waits
 #define FSN_KLOOP_ASM
+// waves 4..7 one weight phase behind waves 0..3 (mlp_dev.hpp, kLag): six ring slots
+// (measured: 510 ms against 432 ms per frame without it - the workgroup barrier of every phase opening re-joins the
+// two groups, so the wave that is not in its epilogue only waits at the next barrier; kept as an experiment switch)
+#ifndef FSN_LAG
+#define FSN_LAG 0
+#endif
+#if FSN_LAG
+#define FSN_NSLOT 6
+#endif
 #include "mlp_dev.hpp"
 #include "ray_dev.hpp"
 
@@ -71,8 +80,14 @@ struct RaySrc {
 #define GRP_HIER (a.n_imp > 0)
 #define GRP_G (S_.Gc)
 #define GRP_R (a.R)
+#ifdef FSN_STAMP
+__device__ unsigned long long g_stamp[256 * 8 * 8];
+#endif
 template <int NT, int PREC>
 __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
+#ifdef FSN_STAMP
+  const uint64_t t_begin = __builtin_amdgcn_s_memtime();
+#endif
   __shared__ __attribute__((aligned(1024))) char smem[kRenderLdsBytes];
   float* auxC = reinterpret_cast<float*>(smem + kRingBytes);
   float* auxF = reinterpret_cast<float*>(smem + kRingBytes + kNetLdsBytes);
@@ -112,6 +127,7 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
     lds_barrier();
     if (GRP_HIER) {
       // ---- density pass of the coarse net (sigma_fn, rendering.py:58-64)
+      st.pass_begin();
       for (int sub = 0; sub < S_.nsubC; ++sub) {
         const int idx = sub * 128 + wave * 16 + (lane & 15);
         const int idc = min(idx, GRP_G * GRP_S - 1);
@@ -121,6 +137,7 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
         mlp_tile<NT, PREC, false>(st, netC, src, ring, sigma, rgb);
         if (lane < 16 && idx < GRP_G * GRP_S) S_.sigC[idx] = sigma;
       }
+      st.pass_end();
       lds_barrier();
       // ---- per-ray weights, inverse-CDF resampling, sorted union (one wave per ray)
       for (int g = wave; g < GRP_G; g += kWaves) {
@@ -137,6 +154,7 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
     }
     const float* edges = GRP_HIER ? S_.edgesF : S_.edgesC;
     // ---- full pass of the fine net (rgb_sigma_fn, rendering.py:76-84)
+    st.pass_begin();
     for (int sub = 0; sub < S_.nsubF; ++sub) {
       const int idx = sub * 128 + wave * 16 + (lane & 15);
       const int idc = min(idx, GRP_G * GRP_SO - 1);
@@ -151,6 +169,7 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
         S_.rgbF[3 * idx + 2] = rgb[2];
       }
     }
+    st.pass_end();
     lds_barrier();
     // ---- volume integration (nerfacc rendering arithmetic, rendering.py:89-96), one wave per ray
     for (int g = wave; g < GRP_G; g += kWaves) {
@@ -171,6 +190,13 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
     lds_barrier();
   }
   st.drain();
+#ifdef FSN_STAMP
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) {
+    unsigned long long* o = g_stamp + (blockIdx.x * 8 + (threadIdx.x >> 6)) * 8;
+    o[0] = __builtin_amdgcn_s_memtime() - t_begin; o[1] = st.t_k; o[2] = st.t_e; o[3] = st.t_n;
+    o[4] = st.t_ko; o[5] = st.t_eo;
+  }
+#endif
 }
 
 #undef GRP_S
@@ -203,6 +229,14 @@ static NetParams net_params(const fsn_mlp_desc& d, const NetGeom& G, const void*
 }  // namespace fsn
 
 using namespace fsn;
+
+#ifdef FSN_STAMP
+extern "C" int fsn_dbg_stamps(unsigned long long* host_out) {
+  FSN_HIP(hipDeviceSynchronize());
+  FSN_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 256 * 8 * 8));
+  return FSN_OK;
+}
+#endif
 
 extern "C" int fsn_render_rays_fused(const fsn_mlp_desc* desc, int prec, const void* blob_coarse,
                                      const void* blob_fine, const fsn_render_args* args, fsn_stream_t stream) {

@@ -33,6 +33,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 UPP = {"X3": 8, "X2": 8}      # units per 16-KiB phase (a unit = 1 KiB high + 1 KiB low parts)
 UB = 2048                      # bytes per unit in the x3 stream layout
+ABL = os.environ.get("FSN_KLOOP_ABL", "")
 LEAD = 2                       # a phase is opened LEAD units before the previous one ends (= prefetch distance D)
 D = 2
 
@@ -57,9 +58,13 @@ def block(mode, nu, off):
         if (off + u + LEAD) % upp == 0:
             # open the next phase: its loads (all but the 2 youngest of this wave) have landed, every wave is past
             # the phase whose slot is restaged; then issue this wave's two 1-KiB LDS-DMA loads of the phase after
-            ins += ["s_waitcnt vmcnt(2)", "s_barrier", "s_mov_b32 %[keep], m0", f"s_mov_b32 m0, %[mv{ev}]", "s_nop 0",
-                    f"global_load_lds_dwordx4 %[voff], %[gb{ev}]",
-                    f"global_load_lds_dwordx4 %[voff], %[gb{ev}] offset:1024", "s_mov_b32 m0, %[keep]"]
+            # (FSN_KLOOP_ABL: timing experiments that drop parts of this - results are then garbage)
+            if "nobarrier" not in ABL:
+                ins += ["s_waitcnt vmcnt(2)", "s_barrier"]
+            if "nodma" not in ABL:
+                ins += ["s_mov_b32 %[keep], m0", f"s_mov_b32 m0, %[mv{ev}]", "s_nop 0",
+                        f"global_load_lds_dwordx4 %[voff], %[gb{ev}]",
+                        f"global_load_lds_dwordx4 %[voff], %[gb{ev}] offset:1024", "s_mov_b32 m0, %[keep]"]
             ev += 1
         read(u + D)
         ins.append(f"s_waitcnt lgkmcnt({D * rpu})")
@@ -110,7 +115,7 @@ def main():
             out.append(emit(mode, 18, off))
         for off in (0, 4):              # first layer: 2 k-steps
             out.append(emit(mode, 4, off))
-    dst = os.path.join(ROOT, "fs-nerf_amd", "csrc", "kloop_gen.hpp")
+    dst = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "fs-nerf_amd", "csrc", "kloop_gen.hpp")
     open(dst, "w").write("\n".join(out))
     print("wrote", dst)
 
