@@ -45,7 +45,11 @@ constexpr int kNSlot = FSN_NSLOT;     // LDS ring slots (phases)
 // leaving the matrix pipe idle at the same time.  Needs two more ring slots (see kLook).
 constexpr int kLag = FSN_LAG;
 #ifndef FSN_LEAD
+#ifdef FSN_KLOOP_ASM_D3
+#define FSN_LEAD 3
+#else
 #define FSN_LEAD 2
+#endif
 #endif
 // A phase is "opened" (its loads waited for, workgroup barrier, next stage issued) kLead units
 // before the previous phase's last unit, so that the first LDS reads of the new phase are issued
@@ -59,8 +63,12 @@ constexpr int kLead = FSN_LEAD;
 constexpr int kLook = kLead > 0 ? kNSlot - 2 - kLag : kNSlot - 1;
 // loads of this wave that may stay in flight when a phase is opened: the lagging waves' share of a phase must have
 // landed one event before they read it themselves (the leading waves read it then), hence "- kLag"
-constexpr int kOpenVmcnt = (kLook - 1 - kLag) * (kPhaseBytes / 1024 / 8);
-static_assert(kOpenVmcnt == 2, "the generated k-loop blocks wait with vmcnt(2)");
+// LDS-DMA is issued by the loader waves 0..kLoaders-1 only (one per SIMD): issuing a 1-KiB load costs the wave
+// 60-185 cycles, and with the workgroup barrier in front of it every wave of the CU used to pay that at the same
+// moment; now the partner wave of each loader (w + 4) runs its MFMAs meanwhile.
+constexpr int kLoaders = 4;
+constexpr int kOpenVmcnt = (kLook - 1 - kLag) * (kPhaseBytes / 1024 / kLoaders);
+static_assert(kOpenVmcnt == 4, "the generated k-loop blocks wait with vmcnt(4)");
 __device__ __forceinline__ uint32_t slot_add(uint32_t s, uint32_t k) {  // (s + k) mod kNSlot, s < kNSlot, k <= kNSlot
   if ((kNSlot & (kNSlot - 1)) == 0) return (s + k) & (kNSlot - 1);
   const uint32_t t = s + k;
@@ -68,7 +76,7 @@ __device__ __forceinline__ uint32_t slot_add(uint32_t s, uint32_t k) {  // (s + 
 }
 constexpr int kWaves = 8;             // wavefronts per workgroup (two per SIMD)
 constexpr int kThreads = 64 * kWaves;
-constexpr int kGldsPerWave = kPhaseBytes / 1024 / kWaves;  // 1-KiB glds instructions per wave per phase
+constexpr int kGldsPerWave = kPhaseBytes / 1024 / kLoaders;  // 1-KiB LDS-DMA instructions per loader wave per phase
 constexpr int kRingBytes = kNSlot * kPhaseBytes;
 constexpr int kAuxCapFloats = 3456;  // LDS reserved per network for biases / heads (8x256 needs 3392)
 constexpr int kTileCols = 128;       // samples per workgroup tile = columns of a T-layout tile (train_fused.hip)
@@ -128,17 +136,21 @@ struct WStream {
     const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(sp >> 32));
     const uint64_t sbase = ((uint64_t)hi << 32) | lo;
     uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %3\n\t"
-        "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(m0v), "s"(sbase)
-        : "memory");
-    static_assert(kGldsPerWave == 2, "stage() issues exactly 2 loads per wave");
+    if (wave < (uint32_t)kLoaders) {
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %2\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %1, %3\n\t"
+          "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+          "global_load_lds_dwordx4 %1, %3 offset:2048\n\t"
+          "global_load_lds_dwordx4 %1, %3 offset:3072\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(voff), "s"(m0v), "s"(sbase)
+          : "memory");
+    }
+    static_assert(kGldsPerWave == 4, "stage() issues exactly 4 loads per loader wave");
     s_ptr += kPhaseBytes;
     s_slot = slot_add(s_slot, 1);
     if (--s_left == 0) advance_pass_();
@@ -232,8 +244,20 @@ __device__ __forceinline__ float from_h(short b) {
   if (F16) return (float)__builtin_bit_cast(_Float16, b);
   return (float)__builtin_bit_cast(__bf16, b);
 }
+// plain C++ form of the high / low split (every mode)
+template <bool F16, bool X3>
+__device__ __forceinline__ void split_store_cpp(const float v[8], Frag& f) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const short h = to_h<F16>(v[j]);
+    f.hi[j] = h;
+    f.lo[j] = X3 ? to_h<F16>(v[j] - from_h<F16>(h)) : (short)0;
+  }
+}
+
 template <bool F16, bool X3>
 __device__ __forceinline__ void split_store(const float v[8], Frag& f) {
+#ifndef FSN_SPLIT_CPP
   if constexpr (F16 && X3) {
     // fp16 high / low parts of a pair of values in three instructions: packed round-to-nearest convert, then
     // low = fp16(v - float(high)) as one mixed-precision fma each (fp32 arithmetic on the fp16 high part, one
@@ -256,6 +280,7 @@ __device__ __forceinline__ void split_store(const float v[8], Frag& f) {
     f.lo = __builtin_bit_cast(s16x8, l);
     return;
   }
+#endif
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const short h = to_h<F16>(v[j]);
@@ -389,8 +414,12 @@ struct AFrag {  // A operand (weights) of one unit
 // A operands are read from the LDS ring one k-step (two units) ahead of their MFMAs; the pair in flight
 // carries over from GEMM to GEMM, tile to tile and pass to pass: on entry to a GEMM `cur` holds its
 // units 0 and 1.
+#ifndef FSN_KLOOP_D
+#define FSN_KLOOP_D 2
+#endif
+constexpr int kKD = FSN_KLOOP_D;  // A-operand units in flight ahead of the MFMAs on the hand-scheduled path
 struct ARing {
-  AFrag cur[3];  // [2]: third set of the hand-scheduled x3 k-loop's rotation
+  AFrag cur[4];  // hand-scheduled path: kKD + 1 sets in rotation; compiler-scheduled prefetch modes: cur[0..1]
 };
 template <int PREC>
 __device__ __forceinline__ void load_afrag(const char* p, AFrag& f) {
@@ -526,7 +555,12 @@ __device__ __forceinline__ void pair_epilogue(const NetDev& net, int tp, const f
       asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
       o = out[0];
 #else
-      split_store<F16, X3>(v, o);
+      // Without a ReLU in front (EPI_CVT) the split would read the MFMA results directly.  hipcc pads the XDL-write ->
+      // VALU-read wait states only for instructions it knows, not for inline asm: the asm form of the split then
+      // reads accumulators whose last MFMA has not retired (found as 1e-3 gradient errors in the backward chain).
+      // The C++ form is used there; behind a ReLU (v_max_i32, padded by hipcc) the asm form is safe.
+      if constexpr (EPI == EPI_CVT) split_store_cpp<F16, X3>(v, o);
+      else split_store<F16, X3>(v, o);
       if constexpr (F16) range_track<EPI == EPI_CVT || EPI == EPI_NONE>(heads.fmax, o.hi);
 #endif
       if (X3) asm volatile("" : "+v"(o.hi), "+v"(o.lo));
@@ -555,32 +589,64 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
 }
 
-#define FSN_KLOOP_OUTS_X3                                                                                      \
-  [c0] "=&v"(c0), [c1] "=&v"(c1), [s0h] "+v"(s0.hi), [s0l] "+v"(s0.lo), [s1h] "+v"(s1.hi), [s1l] "+v"(s1.lo), \
-      [s2h] "+v"(s2.hi), [s2l] "+v"(s2.lo), [keep] "=&s"(keep)
-#define FSN_KLOOP_OUTS_X2 \
-  [c0] "=&v"(c0), [c1] "=&v"(c1), [s0h] "+v"(s0.hi), [s1h] "+v"(s1.hi), [s2h] "+v"(s2.hi), [keep] "=&s"(keep)
+// The two pinned accumulator sets of the hand-scheduled path (E = v[240:247], O = v[248:255]; tile 0 / tile 1).
+struct AccSets {
+  f32x4 e0, e1, o0, o1;
+};
+
+#define FSN_KLOOP_PIN "+{v[240:243]}"(acc.e0), "+{v[244:247]}"(acc.e1), "+{v[248:251]}"(acc.o0), "+{v[252:255]}"(acc.o1)
+#if FSN_KLOOP_D == 3
+#define FSN_KLOOP_SETS_X3                                                                                        \
+  [s0h] "+v"(s0.hi), [s0l] "+v"(s0.lo), [s1h] "+v"(s1.hi), [s1l] "+v"(s1.lo), [s2h] "+v"(s2.hi), [s2l] "+v"(s2.lo), \
+      [s3h] "+v"(s3.hi), [s3l] "+v"(s3.lo), [keep] "=&s"(keep)
+#define FSN_KLOOP_SETS_X2 [s0h] "+v"(s0.hi), [s1h] "+v"(s1.hi), [s2h] "+v"(s2.hi), [s3h] "+v"(s3.hi), [keep] "=&s"(keep)
+#else
+#define FSN_KLOOP_SETS_X3                                                                                        \
+  [s0h] "+v"(s0.hi), [s0l] "+v"(s0.lo), [s1h] "+v"(s1.hi), [s1l] "+v"(s1.lo), [s2h] "+v"(s2.hi), [s2l] "+v"(s2.lo), \
+      [keep] "=&s"(keep)
+#define FSN_KLOOP_SETS_X2 [s0h] "+v"(s0.hi), [s1h] "+v"(s1.hi), [s2h] "+v"(s2.hi), [keep] "=&s"(keep)
+#endif
+#define FSN_KLOOP_EPI_OUTS                                                                                    \
+  [oh0] "=&v"(oh[0]), [oh1] "=&v"(oh[1]), [oh2] "=&v"(oh[2]), [oh3] "=&v"(oh[3]), [ol0] "=&v"(ol[0]),          \
+      [ol1] "=&v"(ol[1]), [ol2] "=&v"(ol[2]), [ol3] "=&v"(ol[3]), [fmax] "+v"(fmax), [tmp] "=&v"(tmp)
 #define FSN_B(k) bsel<k, KS_ACT, KS_ENC>(act, enc)
-#define FSN_KLOOP_INS                                                                                               \
-  [z0] "v"(z0), [z1] "v"(z1), [b0h] "v"(FSN_B(0).hi), [b0l] "v"(FSN_B(0).lo), [b1h] "v"(FSN_B(1).hi),              \
-      [b1l] "v"(FSN_B(1).lo), [b2h] "v"(FSN_B(2).hi), [b2l] "v"(FSN_B(2).lo), [b3h] "v"(FSN_B(3).hi),              \
-      [b3l] "v"(FSN_B(3).lo), [b4h] "v"(FSN_B(4).hi), [b4l] "v"(FSN_B(4).lo), [b5h] "v"(FSN_B(5).hi),              \
-      [b5l] "v"(FSN_B(5).lo), [b6h] "v"(FSN_B(6).hi), [b6l] "v"(FSN_B(6).lo), [b7h] "v"(FSN_B(7).hi),              \
-      [b7l] "v"(FSN_B(7).lo), [b8h] "v"(FSN_B(8).hi), [b8l] "v"(FSN_B(8).lo), [b9h] "v"(FSN_B(9).hi),              \
-      [b9l] "v"(FSN_B(9).lo), [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [voff] "v"(voff),    \
+#define FSN_KLOOP_INS                                                                                            \
+  [b0h] "v"(FSN_B(0).hi), [b0l] "v"(FSN_B(0).lo), [b1h] "v"(FSN_B(1).hi), [b1l] "v"(FSN_B(1).lo),                \
+      [b2h] "v"(FSN_B(2).hi), [b2l] "v"(FSN_B(2).lo), [b3h] "v"(FSN_B(3).hi), [b3l] "v"(FSN_B(3).lo),            \
+      [b4h] "v"(FSN_B(4).hi), [b4l] "v"(FSN_B(4).lo), [b5h] "v"(FSN_B(5).hi), [b5l] "v"(FSN_B(5).lo),            \
+      [b6h] "v"(FSN_B(6).hi), [b6l] "v"(FSN_B(6).lo), [b7h] "v"(FSN_B(7).hi), [b7l] "v"(FSN_B(7).lo),            \
+      [b8h] "v"(FSN_B(8).hi), [b8l] "v"(FSN_B(8).lo), [b9h] "v"(FSN_B(9).hi), [b9l] "v"(FSN_B(9).lo),            \
+      [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [abn] "v"(abn), [voff] "v"(voff),          \
       [mv0] "s"(mv[0]), [gb0] "s"(gb[0]), [mv1] "s"(mv[1]), [gb1] "s"(gb[1]), [mv2] "s"(mv[2]), [gb2] "s"(gb[2])
-#define FSN_KLOOP_CASE(MODE, NU_, OFF_)                                                                          \
-  if constexpr (NU == NU_ && OFF == OFF_) {                                                                      \
-    constexpr int EV = FSN_KLOOP_##MODE##_##NU_##_##OFF_##_EVENTS, NP = FSN_KLOOP_##MODE##_##NU_##_##OFF_##_PHASES; \
-    kloop_plan<EV, NP>(st, a, mv, gb);                                                                           \
-    if constexpr (F16)                                                                                           \
-      asm volatile(FSN_KLOOP_##MODE##_##NU_##_##OFF_("v_mfma_f32_16x16x32_f16")                                \
-                   : FSN_KLOOP_OUTS_##MODE : FSN_KLOOP_INS : "memory");                                          \
-    else                                                                                                         \
-      asm volatile(FSN_KLOOP_##MODE##_##NU_##_##OFF_("v_mfma_f32_16x16x32_bf16")                               \
-                   : FSN_KLOOP_OUTS_##MODE : FSN_KLOOP_INS : "memory");                                          \
-    st.opened(EV);                                                                                               \
+// one asm statement: text variant TXT (both MFMA element types), output list OUTS
+#define FSN_KLOOP_EMIT(TXT, OUTS)                                                                       \
+  do {                                                                                                  \
+    if constexpr (F16) asm volatile(TXT("v_mfma_f32_16x16x32_f16") : OUTS : FSN_KLOOP_INS : "memory");  \
+    else asm volatile(TXT("v_mfma_f32_16x16x32_bf16") : OUTS : FSN_KLOOP_INS : "memory");               \
+  } while (0)
+#define FSN_KLOOP_CASE(MODE, NU_, OFF_)                                                                         \
+  if constexpr (NU == NU_ && OFF == OFF_) {                                                                     \
+    constexpr int EV = FSN_KLOOP_##NU_##_##OFF_##_EVENTS, NP = FSN_KLOOP_##NU_##_##OFF_##_PHASES;               \
+    kloop_plan<EV, NP>(st, a, mv, gb);                                                                          \
+    if constexpr (EK == 0 && PAR == 0)                                                                          \
+      FSN_KLOOP_EMIT(FSN_KLOOP_##MODE##_##NU_##_##OFF_##_N0, FSN_KLOOP_PIN FSN_COMMA FSN_KLOOP_SETS_##MODE);    \
+    else if constexpr (EK == 0)                                                                                 \
+      FSN_KLOOP_EMIT(FSN_KLOOP_##MODE##_##NU_##_##OFF_##_N1, FSN_KLOOP_PIN FSN_COMMA FSN_KLOOP_SETS_##MODE);    \
+    else if constexpr (EK == 1 && PAR == 0)                                                                     \
+      FSN_KLOOP_EMIT(FSN_KLOOP_##MODE##_##NU_##_##OFF_##_R0,                                                    \
+                     FSN_KLOOP_PIN FSN_COMMA FSN_KLOOP_SETS_##MODE FSN_COMMA FSN_KLOOP_EPI_OUTS);               \
+    else if constexpr (EK == 1)                                                                                 \
+      FSN_KLOOP_EMIT(FSN_KLOOP_##MODE##_##NU_##_##OFF_##_R1,                                                    \
+                     FSN_KLOOP_PIN FSN_COMMA FSN_KLOOP_SETS_##MODE FSN_COMMA FSN_KLOOP_EPI_OUTS);               \
+    else if constexpr (PAR == 0)                                                                                \
+      FSN_KLOOP_EMIT(FSN_KLOOP_##MODE##_##NU_##_##OFF_##_C0,                                                    \
+                     FSN_KLOOP_PIN FSN_COMMA FSN_KLOOP_SETS_##MODE FSN_COMMA FSN_KLOOP_EPI_OUTS);               \
+    else                                                                                                        \
+      FSN_KLOOP_EMIT(FSN_KLOOP_##MODE##_##NU_##_##OFF_##_C1,                                                    \
+                     FSN_KLOOP_PIN FSN_COMMA FSN_KLOOP_SETS_##MODE FSN_COMMA FSN_KLOOP_EPI_OUTS);               \
+    st.opened(EV);                                                                                              \
   }
+#define FSN_COMMA ,
 
 // phase addresses and stage descriptors of a block with EV openings touching NP phases; unused slots repeat slot 0
 template <int EV, int NP>
@@ -592,6 +658,7 @@ __device__ __forceinline__ void kloop_plan(WStream& st, uint32_t (&a)[4], uint32
     if (e < EV) st.next_stage(mv[e], gb[e]);
     else { mv[e] = mv[0]; gb[e] = gb[0]; }
   }
+  if (EV == 0) { mv[0] = mv[1] = mv[2] = 0; gb[0] = gb[1] = gb[2] = 0; }
 }
 
 // B operand of k-step K: activations first, then the encoding; K past the last k-step repeats the last one (the
@@ -603,15 +670,20 @@ __device__ __forceinline__ const Frag& bsel(const Frag (&act)[NACT], const Frag 
   else return enc[kk - KS_ACT];
 }
 
-// One output pair: NU = 2 x k-steps units starting OFF units into the current phase; z0/z1: initial accumulators;
+// One output pair: NU = 2 x k-steps units starting OFF units into the current phase.  The pair accumulates in
+// set E (PAR 0) or O (PAR 1), which holds its bias on entry; the other set receives the next pair's bias (abn =
+// its LDS address).  EK 1 / 2: the other set holds the previous pair's finished accumulators on entry and its
+// epilogue (1: ReLU + fp16 split, 2: split only) runs inside the stream -> prev (high / low parts), fmax.
 // s0,s1: A sets holding units 0,1 on entry; on exit units NU, NU+1 sit in sets (NU % 3), ((NU+1) % 3) of (s0,s1,s2).
-template <bool F16, bool TWO, int KS_ACT, int KS_ENC, int OFF, int NACT, int NENC>
+template <bool F16, bool TWO, int KS_ACT, int KS_ENC, int OFF, int EK, int PAR, int NACT, int NENC>
 __device__ __forceinline__ void kloop_block(WStream& st, const Frag (&act)[NACT], const Frag (&enc)[NENC],
-                                            const f32x4& z0, const f32x4& z1, f32x4& c0, f32x4& c1, AFrag& s0,
-                                            AFrag& s1, AFrag& s2) {
+                                            AccSets& acc, uint32_t abn, AFrag& s0, AFrag& s1, AFrag& s2, AFrag& s3,
+                                            Frag& prev, uint32_t& fmax) {
   constexpr int NU = 2 * (KS_ACT + KS_ENC);
-  uint32_t a[4], mv[3], keep;
+  uint32_t a[4], mv[3], keep, tmp;
   uint64_t gb[3];
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+  u32x4 oh, ol;
   const uint32_t voff = (threadIdx.x >> 6) * (kGldsPerWave * 1024) + (threadIdx.x & 63) * 16;
   if constexpr (!TWO) {
     FSN_KLOOP_CASE(X3, 16, 0)
@@ -634,9 +706,13 @@ __device__ __forceinline__ void kloop_block(WStream& st, const Frag (&act)[NACT]
     FSN_KLOOP_CASE(X2, 4, 0)
     FSN_KLOOP_CASE(X2, 4, 4)
   }
+  if constexpr (EK != 0) {
+    prev.hi = __builtin_bit_cast(s16x8, oh);
+    prev.lo = __builtin_bit_cast(s16x8, ol);
+  }
   (void)keep;
+  (void)tmp;
 }
-
 
 // NP_OUT output pairs (32 features = two 16-row tiles); KS_ACT k-steps (of 32) from `act`, KS_ENC
 // from `enc`; units are consumed in (pair, k-step, half) order starting phase-aligned.  Epilogue
@@ -651,7 +727,7 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
                                            const Frag (&enc)[NENC], Frag (&out)[NOUT], Heads& heads, ARing& ring,
                                            int g, HK& hk) {
   constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
-  static_assert(kLead == 2, "the A-operand prefetch distance (one k-step = two units) equals the phase lead");
+  static_assert(kLead >= 2, "the A-operand prefetch distance (one k-step = two units) must not exceed the phase lead");
   constexpr bool PREFETCH = !X3;
 #ifdef FSN_X3_PF1
   constexpr bool kX3Pf1 = X3;
@@ -665,54 +741,86 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
   static_assert(KS_ACT <= NACT && KS_ENC <= NENC, "operand arrays too small");
   const float* bias = net.aux + aux_bias;
   if constexpr (kKloopAsm && X3 && (KS == 8 || KS == 10 || KS == 9 || KS == 2) &&
-                (KS_ACT == 8 || (KS_ACT == 0 && NP_OUT == 8))) {
+                (KS_ACT == 8 || (KS_ACT == 0 && NP_OUT == 8)) && !HK::kZeroInit) {
     // hand-scheduled path (256-wide networks): ring.cur[0], cur[1] hold this GEMM's units 0 and 1 on entry and the
-    // next GEMM's on exit; inside, the three A sets rotate by NU units per pair (compile-time indices)
+    // next GEMM's on exit; inside, the three A sets rotate by NU units per pair (compile-time indices).  The pairs
+    // alternate between two pinned accumulator sets; with a plain epilogue (ReLU / none + fp16 split, no hook) the
+    // epilogue of pair tp-1 runs inside the instruction stream of pair tp (kloop_gen.hpp) and only the last pair's
+    // runs on its own.
     constexpr int NU = 2 * KS;
     static_assert(TOTAL % UPP == 0, "a GEMM of the hand-scheduled path ends on a phase boundary");
-    static_for<NP_OUT>([&](auto TP) __attribute__((always_inline)) {
-      constexpr int tp = decltype(TP)::value;
-      constexpr int R0 = (tp * NU) % 3, OFF = (tp * NU) % UPP;
-      f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
-      if constexpr (!HK::kZeroInit) {
-        z0 = *reinterpret_cast<const f32x4*>(bias + 32 * tp + 4 * g);
-        z1 = *reinterpret_cast<const f32x4*>(bias + 32 * tp + 16 + 4 * g);
-      }
-      hk.pre(tp);
+    // Deferred epilogue (kloop_gen.hpp, R / C variants): the epilogue of pair tp-1 runs as one burst in the middle of
+    // pair tp's instruction stream.  Only waves 4..7 do this; their SIMD partners (waves 0..3) run each pair's
+    // epilogue right after the pair, so on every SIMD the two epilogues are half a pair apart and each coincides
+    // with the partner's MFMAs instead of with the partner's epilogue (all waves are kept in step by the weight
+    // stream's barriers).  Interleaving the epilogue one instruction per MFMA was measured slower (no issue slots
+    // to spare beside two waves' MFMAs, A reads and waits).
+#ifndef FSN_DEFER_EPI  // (measured slower too: 435 ms against 420 ms per frame; kept as an experiment switch)
+    constexpr bool kCanDefer = false;
+#else
+    constexpr bool kCanDefer = F16 && std::is_same<HK, NoHook>::value && (EPI == EPI_RELU_CVT || EPI == EPI_CVT) && KS > 2;
+#endif
+    constexpr int EKD = EPI == EPI_RELU_CVT ? 1 : 2;
+    AccSets acc;
+    acc.e0 = *reinterpret_cast<const f32x4*>(bias + 4 * g);
+    acc.e1 = *reinterpret_cast<const f32x4*>(bias + 16 + 4 * g);
+    acc.o0 = acc.e0;
+    acc.o1 = acc.e1;
+    const uint32_t bias_lds = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)(bias + 4 * g);
+    auto run = [&](auto EKS_) __attribute__((always_inline)) {
+      constexpr int EKS = decltype(EKS_)::value;  // 0: epilogue after each pair; 1 / 2: deferred into the next pair
+      static_for<NP_OUT>([&](auto TP) __attribute__((always_inline)) {
+        constexpr int tp = decltype(TP)::value;
+        constexpr int NS = kKD + 1;  // A register sets
+        constexpr int R0 = (tp * NU) % NS, OFF = (tp * NU) % UPP, PAR = tp & 1;
+        constexpr int EK = tp == 0 ? 0 : EKS;
+        hk.pre(tp);
 #if defined(FSN_PRIO) && FSN_PRIO == 4
-      if (__builtin_amdgcn_readfirstlane(threadIdx.x) & 256) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        if (__builtin_amdgcn_readfirstlane(threadIdx.x) & 256) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
 #endif
-      f32x4 acc0, acc1;
 #ifdef FSN_STAMP
-      const uint64_t ts0 = __builtin_amdgcn_s_memtime();
+        const uint64_t ts0 = __builtin_amdgcn_s_memtime();
 #endif
-      kloop_block<F16, PREC == 6, KS_ACT, KS_ENC, OFF>(st, act, enc, z0, z1, acc0, acc1, ring.cur[R0],
-                                                       ring.cur[(R0 + 1) % 3], ring.cur[(R0 + 2) % 3]);
+        const uint32_t abn = bias_lds + 128u * (tp + 1 < NP_OUT ? tp + 1 : tp);  // (last pair: a harmless reload)
+        kloop_block<F16, PREC == 6, KS_ACT, KS_ENC, OFF, EK, PAR>(
+            st, act, enc, acc, abn, ring.cur[R0], ring.cur[(R0 + 1) % NS], ring.cur[(R0 + 2) % NS],
+            ring.cur[(R0 + 3) % NS == R0 ? 3 : (R0 + 3) % NS], out[tp > 0 && tp - 1 < NOUT ? tp - 1 : 0], heads.fmax);
 #ifdef FSN_STAMP
-      const uint64_t ts1 = __builtin_amdgcn_s_memtime();
+        const uint64_t ts1 = __builtin_amdgcn_s_memtime();
 #endif
-      pair_epilogue<PREC, NP_OUT, EPI>(net, tp, acc0, acc1, out, heads, g, hk);
-#ifdef FSN_STAMP
-      {
-        const uint64_t ts2 = __builtin_amdgcn_s_memtime();
-        if (KS == 8) {  // the 256 -> 256 GEMMs
-          st.t_k += ts1 - ts0;
-          st.t_e += ts2 - ts1;
-          st.t_n += 1;
-        } else {  // first layer, skip layer, branch
-          st.t_ko += ts1 - ts0;
-          st.t_eo += ts2 - ts1;
+        if constexpr (EKS == 0 || tp == NP_OUT - 1) {
+          if constexpr (PAR == 0) pair_epilogue<PREC, NP_OUT, EPI>(net, tp, acc.e0, acc.e1, out, heads, g, hk);
+          else pair_epilogue<PREC, NP_OUT, EPI>(net, tp, acc.o0, acc.o1, out, heads, g, hk);
         }
-      }
+#ifdef FSN_STAMP
+        {
+          const uint64_t ts2 = __builtin_amdgcn_s_memtime();
+          if (KS == 8) {  // the 256 -> 256 GEMMs
+            st.t_k += ts1 - ts0;
+            st.t_e += ts2 - ts1;
+            st.t_n += 1;
+          } else {  // first layer, skip layer, branch
+            st.t_ko += ts1 - ts0;
+            st.t_eo += ts2 - ts1;
+          }
+        }
 #endif
-    });
-    constexpr int RE = TOTAL % 3;  // sets holding the next GEMM's units 0, 1
-    if constexpr (RE == 1) {
-      const AFrag t = ring.cur[0];
-      ring.cur[0] = ring.cur[1]; ring.cur[1] = ring.cur[2]; ring.cur[2] = t;
-    } else if constexpr (RE == 2) {
-      const AFrag t = ring.cur[1];
-      ring.cur[1] = ring.cur[0]; ring.cur[0] = ring.cur[2]; ring.cur[2] = t;
+      });
+    };
+    if constexpr (kCanDefer) {
+      if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) run(std::integral_constant<int, EKD>{});
+      else run(std::integral_constant<int, 0>{});
+    } else {
+      run(std::integral_constant<int, 0>{});
+    }
+    // bring the sets holding the next GEMM's first kKD units back to cur[0..kKD-1]
+    constexpr int RE = TOTAL % (kKD + 1);
+    if constexpr (RE != 0) {
+      AFrag t[kKD + 1];
+#pragma unroll
+      for (int i = 0; i <= kKD; ++i) t[i] = ring.cur[(RE + i) % (kKD + 1)];
+#pragma unroll
+      for (int i = 0; i <= kKD; ++i) ring.cur[i] = t[i];
     }
     return;
   }
@@ -806,9 +914,10 @@ template <int PREC, int NT = 0>
 __device__ __forceinline__ void prime_ring(const WStream& st, ARing& ring) {
   constexpr int UB = (PREC & 1) == 0 ? 2048 : 1024;
   if (kKloopAsm && (PREC & 1) == 0 && NT == 8) {  // hand-scheduled x3 / x2 path: units 0 and 1 of the first GEMM
-    load_afrag<PREC>(st.n_base, ring.cur[0]);
-    load_afrag<PREC>(st.n_base + UB, ring.cur[1]);
-    ring.cur[2] = ring.cur[0];
+#pragma unroll
+    for (int i = 0; i < kKD; ++i) load_afrag<PREC>(st.n_base + i * UB, ring.cur[i]);
+#pragma unroll
+    for (int i = kKD; i < 4; ++i) ring.cur[i] = ring.cur[0];
     return;
   }
 #ifdef FSN_X3_PF1

@@ -7,10 +7,9 @@
 // group to ray group; per-ray scans/reductions are done by one wavefront per ray (ray_dev.hpp).
 // HBM traffic is the rays in and the requested outputs out.
 #include "common.hpp"
-// wave priority (s_setprio): 2 for the per-pair epilogue (conversions), and in the MFMA k-loop 1 for waves 4..7 / 0 for
-// waves 0..3 (waves w and w+4 share a SIMD): +1.3 % and a further +0.5 % in this kernel (A/B on MI355X; the standalone
-// MLP kernel loses 1.6 % with priority changes and leaves them off)
-#define FSN_PRIO 4
+// Wave priorities (s_setprio around the k-loop / the pair epilogue, FSN_PRIO) are off: round 1's "+1.8 %" was measured
+// with a lane-divergent condition, which compiles to both s_setprio instructions executed by every wave; with the
+// wave-uniform form the asymmetric priorities cost 2.3 % (A/B on MI355X, tools/ab_fused.py).
 // hand-scheduled k-loop of the x3 modes (kloop_gen.hpp): A operands two units ahead, counted waits
 #define FSN_KLOOP_ASM
 // waves 4..7 one weight phase behind waves 0..3 (mlp_dev.hpp, kLag): six ring slots

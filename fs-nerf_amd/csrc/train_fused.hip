@@ -24,6 +24,9 @@
 // x3 modes: pinned one-unit-ahead LDS prefetch of the A operands (mlp_dev.hpp).  +6 % on these kernels; the fused
 // render kernel keeps the compiler's own read placement (with its larger live state the pinned form spills more).
 #define FSN_X3_PF1
+#ifndef FSN_WG_SPLIT
+#define FSN_WG_SPLIT split_store
+#endif
 #include "mlp_dev.hpp"
 #include "mlp_layout.hpp"
 #include "train_internal.hpp"
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { v[j] = braw[it][0][j]; v[4 + j] = braw[it][1][j]; }
         Frag f;
-        split_store<F16, X3>(v, f);
+        FSN_WG_SPLIT<F16, X3>(v, f);
         const int addr = ((((R >> 5) * 2 + (sg & 1)) * 64) + (sg >> 1) * 32 + (R & 31)) * 16;  // sg = 2 kg + ks
         *reinterpret_cast<s16x8*>(&lds[buf][0][addr]) = f.hi;
         if (X3) *reinterpret_cast<s16x8*>(&lds[buf][1][addr]) = f.lo;
@@ -518,7 +521,7 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgArgs a) {
         for (int j = 0; j < 4; ++j) { v[j] = araw[ti][ks][0][j]; v[4 + j] = araw[ti][ks][1][j]; }
 #pragma unroll
         for (int j = 0; j < 8; ++j) bsum[ti] += v[j];
-        split_store<F16, X3>(v, af[ti][ks]);
+        FSN_WG_SPLIT<F16, X3>(v, af[ti][ks]);
       }
     if (ci + 1 < nchunk) load_chunk(ci + 1);  // next chunk's global loads fly under the MFMAs
     if (active) {
