@@ -156,9 +156,7 @@ def composite_packed(sigmas: Tensor, rgbs: Tensor, t_starts: Tensor, t_ends: Ten
                      n_rays: int, bkgd=None):
     sig, rgb = _f32(sigmas, "sigmas"), _f32(rgbs, "rgbs")
     t0, t1 = _f32(t_starts, "t_starts"), _f32(t_ends, "t_ends")
-    ri = ray_indices.contiguous()
-    if ri.dtype != torch.int64:
-        ri = ri.long()
+    ri = _i64(ray_indices, "ray_indices")
     N = sig.numel()
     dev = t0.device
     colors = torch.empty(n_rays, 3, device=dev)

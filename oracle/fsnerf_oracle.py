@@ -128,31 +128,47 @@ def freq_mask(d_in: int, n_freqs: int, ratio: float) -> Tensor:
 
 
 # ------------------------------------------------------------------------ MLP
+def round_to(t: Tensor, fmt: Optional[str]) -> Tensor:
+    """Round every element to the nearest bfloat16 / float16 value (ties to even) and return it in t's dtype: the
+    rounding a 16-bit MFMA operand undergoes.  `fmt` None = identity."""
+    if fmt is None:
+        return t
+    return t.to({"bf16": torch.bfloat16, "fp16": torch.float16}[fmt]).to(t.dtype)
+
+
 def nerf_forward(sd: Dict[str, Tensor], x: Tensor, dirs: Optional[Tensor], *,
                  n_layers: int, skip: Sequence[int], n_freqs: int, n_freqs_dir: int,
                  log_space: bool = True, log_space_dir: Optional[bool] = None,
-                 pos_mask: Optional[Tensor] = None, dir_mask: Optional[Tensor] = None) -> Tensor:
+                 pos_mask: Optional[Tensor] = None, dir_mask: Optional[Tensor] = None,
+                 emulate: Optional[str] = None) -> Tensor:
     """NeRF MLP forward from a reference-format state_dict.
     Follows `src/core/models.py:111-143`: relu(layer_i(h)); after layer i in `skip`
     h = cat([h, x_in]); sigma head without activation; connection (no activation);
-    cat([feat, dir_enc]); relu(branch); sigmoid(rgb); returns [N,1] or [N,4]=[rgb,sigma]."""
+    cat([feat, dir_enc]); relu(branch); sigmoid(rgb); returns [N,1] or [N,4]=[rgb,sigma].
+    `emulate` = "bf16" / "fp16" (BASELINE config 5, "bf16 weights/activations"): the same math with the operand
+    rounding of a single-pass 16-bit matrix-core kernel restated on the CPU - every Linear layer's weight and input
+    are rounded to that format before the product, products and sums are taken in x's dtype (the kernel accumulates
+    in float32), biases, activations and the two heads (sigma: 256 -> 1, rgb: 128 -> 3, evaluated on the unrounded
+    accumulators) stay in x's dtype.  None = the reference arithmetic."""
     if log_space_dir is None:
         log_space_dir = log_space
     dt = x.dtype
     W = lambda k: sd[k].to(dt)
+    q = lambda t: round_to(t, emulate)
+    lin = lambda h, k: q(h) @ q(W(k + ".weight")).T + W(k + ".bias")  # a matrix-core GEMM
     x_in = posenc(x, n_freqs, log_space, pos_mask)
     h = x_in
     for i in range(n_layers):
-        h = torch.relu(h @ W(f"layers.{i}.weight").T + W(f"layers.{i}.bias"))
+        h = torch.relu(lin(h, f"layers.{i}"))
         if i in skip:
             h = torch.cat([h, x_in], dim=-1)
-    sigma = h @ W("sigma.weight").T + W("sigma.bias")
+    sigma = h @ W("sigma.weight").T + W("sigma.bias")  # fp32 dot product on the accumulators
     if dirs is None:
         return sigma
-    f = h @ W("connection.weight").T + W("connection.bias")
+    f = lin(h, "connection")
     d_in = posenc(dirs, n_freqs_dir, log_space_dir, dir_mask)
     f = torch.cat([f, d_in], dim=-1)
-    f = torch.relu(f @ W("branch.weight").T + W("branch.bias"))
+    f = torch.relu(lin(f, "branch"))
     rgb = torch.sigmoid(f @ W("rgb.weight").T + W("rgb.bias"))
     return torch.cat([rgb, sigma], dim=-1)
 
@@ -309,7 +325,7 @@ def render_rays_oracle(rays_o: Tensor, rays_d: Tensor, sd_coarse: Dict[str, Tens
                        n_samples: int, n_importance: int = 0, u: Optional[Tensor] = None,
                        u_fine: Optional[Tensor] = None, white_bkgd: bool = False,
                        pos_mask: Optional[Tensor] = None, dir_mask: Optional[Tensor] = None,
-                       edges_override: Optional[Tensor] = None):
+                       edges_override: Optional[Tensor] = None, emulate: Optional[str] = None):
     """The whole path in the reference's operator order (`src/render/rendering.py:58-107`):
       1. intervals from `stratified_edges` (fills the `estimator.sampling` slot, `:66-74`);
       2. density-only pass sigma_fn: x = o + d*(t0+t1)/2; sigma = model(x)       (`:58-64`)
@@ -323,12 +339,12 @@ def render_rays_oracle(rays_o: Tensor, rays_d: Tensor, sd_coarse: Dict[str, Tens
     extras additionally holds "edges" [R,S'+1] and, when hierarchical, "weights_coarse" [R,S].
     `edges_override` [R,S'+1] replaces the result of steps 1-3 for step 4 (tests use it to check the
     full pass + integration on exactly the sample set another implementation produced, because
-    inverse-CDF resampling is ill-conditioned where the coarse pdf is ~0)."""
+    inverse-CDF resampling is ill-conditioned where the coarse pdf is ~0).  `emulate`: see nerf_forward."""
     R = rays_o.shape[0]
     dt = rays_o.dtype
     mk = dict(n_layers=cfg["n_layers"], skip=cfg["skip"], n_freqs=cfg["n_freqs"],
               n_freqs_dir=cfg["n_freqs_dir"], log_space=cfg.get("log_space", True),
-              pos_mask=pos_mask, dir_mask=dir_mask)
+              pos_mask=pos_mask, dir_mask=dir_mask, emulate=emulate)
     edges = stratified_edges(near, far, n_samples, R, u, dtype=dt)
     w_coarse = None
     if n_importance > 0:

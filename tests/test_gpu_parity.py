@@ -302,8 +302,10 @@ def _check_render(out, want, what):
     close(op, wop, atol=1e-5 * wmax, what=what + " opacity")
     # depth = sum(w t)/max(sum w, eps): compare where it is well conditioned
     cond = wex["weights"].abs().sum(-1, keepdim=True) / wop.abs().clamp(min=1e-12)
-    dep_ok = ((cond < 50.0) & (wop > 1e-3)).squeeze(-1)
-    assert dep_ok.float().mean().item() > 0.5
+    # depth = sum(w t) / max(sum w, eps): the absolute tolerance scales with the ray's condition number
+    # sum|w| / |sum w| (raw sigma of both signs gives mixed-sign weights); rays of ~zero opacity divide by ~eps
+    dep_ok = (wop > 1e-3).squeeze(-1)
+    assert dep_ok.float().mean().item() > 0.95, "test scene: nearly every ray must carry opacity"
     close(dep.cpu()[dep_ok], wdep[dep_ok], atol=(1e-4 * cond[dep_ok].clamp(min=1.0)).numpy(), what=what + " depth_map")
     assert torch.equal(ri.cpu(), wri)
     close(tv, wtv, rtol=0, atol=0, what=what + " t_vals")
@@ -332,7 +334,11 @@ def test_render_rays_coarse_only(dev, golden_dir, tag, R, S, white, jit):
 @pytest.mark.parametrize("tag,R,S,NI,two_nets", [("8x256", 130, 64, 128, True), ("4x128", 1001, 64, 128, False),
                                                  ("4x128", 33, 128, 256, True)])
 def test_render_rays_hierarchical(dev, golden_dir, tag, R, S, NI, two_nets):
+    """End to end (coarse pass -> weights -> resampling -> fine pass -> integration in one launch, nothing substituted)
+    against the float64 truth with the float32 oracle as yardstick (tests/test_parity_fp64.py: error <= 2 x the
+    float32 oracle's, inside 1e-4 wherever the float32 oracle is), plus the intermediate results the path exposes."""
     from fs_nerf_amd.render import rendering as Rm
+    from test_parity_fp64 import assert_parity, oracle as run_oracle
     _, sd = load_sd(golden_dir, tag)
     sd_f = None
     if two_nets:
@@ -344,25 +350,24 @@ def test_render_rays_hierarchical(dev, golden_dir, tag, R, S, NI, two_nets):
     o, d, gen = _rays(R, 7)
     u = torch.rand(R, generator=gen)
     uf = torch.rand(R, NI, generator=gen)
-    want = O.render_rays_oracle(o, d, sd, sd_f, CFG[tag], near=2.0, far=6.0, n_samples=S, n_importance=NI, u=u,
-                                u_fine=uf, white_bkgd=True)
+    kw = dict(near=2.0, far=6.0, n_samples=S, n_importance=NI, u=u, u_fine=uf, white_bkgd=True)
+    truth = run_oracle(o, d, sd, sd_f, CFG[tag], torch.float64, **kw)
+    want = run_oracle(o, d, sd, sd_f, CFG[tag], torch.float32, **kw)
     est = Rm.StratifiedEstimator(2.0, 6.0, S, NI)
     out = Rm.render_rays(o, d, est, mc, train=False, white_bkgd=True, device=dev, model_fine=mf, u=u.to(dev),
                          u_fine=uf.to(dev))
-    # stage 1 (coarse density pass -> weights -> resampling): weights strictly; the resampled edges up to
-    # the ill-conditioning of the inverse CDF (dt/du = bin width / pdf ~ 4e3 where the coarse pdf is ~0,
-    # so last-bit differences of the weights move a few importance samples inside empty space)
-    wc = want[0][3]["weights_coarse"]
-    close(out[0][3]["weights_coarse"], wc, atol=1e-5 * max(float(wc.abs().max()), 1.0), what="coarse weights")
-    e, we = out[0][3]["edges"].cpu(), want[0][3]["edges"]
+    assert_parity(out, want, truth, f"{tag} {S}+{NI}")
+    # stage 1 on its own: coarse weights and the resampled interval edges, same yardstick
+    wt = truth[0][3]["weights_coarse"]
+    e_hip = (out[0][3]["weights_coarse"].cpu().double() - wt).abs()
+    e_o32 = (want[0][3]["weights_coarse"].double() - wt).abs()
+    assert float(e_hip.max()) <= 2.0 * float(e_o32.max()) + 3e-7, (float(e_hip.max()), float(e_o32.max()))
+    e, et = out[0][3]["edges"].cpu().double(), truth[0][3]["edges"]
     assert bool((e[:, 1:] >= e[:, :-1]).all())
-    moved = (e - we).abs() > 1e-4
-    assert moved.float().mean().item() < 5e-3, f"{int(moved.sum())} of {moved.numel()} edges moved"
-    close(out[0][0], want[0][0], rtol=2e-3, atol=2e-3, what="rgb_map, own sample sets")
-    # stage 2 (fine pass + integration) strictly, on exactly the sample set the kernel produced
-    want2 = O.render_rays_oracle(o, d, sd, sd_f, CFG[tag], near=2.0, far=6.0, n_samples=S, n_importance=NI, u=u,
-                                 u_fine=uf, white_bkgd=True, edges_override=e)
-    _check_render(out, want2, f"{tag} {S}+{NI}")
+    ee_hip, ee_o32 = (e - et).abs(), (want[0][3]["edges"].double() - et).abs()
+    assert float(ee_hip.max()) <= 2.0 * float(ee_o32.max()) + 3e-6, (float(ee_hip.max()), float(ee_o32.max()))
+    assert float(np.percentile(ee_hip.numpy(), 99)) <= 2.0 * float(np.percentile(ee_o32.numpy(), 99)) + 1e-6
+    assert torch.equal(out[1].cpu(), want[1])
 
 
 def test_render_rays_generic_model_matches_fused(dev, golden_dir):
@@ -524,23 +529,4 @@ def test_config4_ndc_forward_facing(dev, golden_dir):
     _check_render(out, want, "config 4 (ndc)")
 
 
-def test_config5_bf16_128_256(dev, golden_dir):
-    """configs[4] shape: 128+256 samples, bf16 weights/activations (single MFMA pass).  Tolerance relaxed and
-    stated: |rgb - fp32 oracle| <= 3e-2 on the kernel's own sample set (bf16 has 8 mantissa bits)."""
-    from fs_nerf_amd.render import rendering as Rm
-    _, sd = load_sd(golden_dir, "8x256")
-    m = make_model(sd, 8, 256, [4], dev, precision="bf16")
-    o, d, gen = _rays(96, 5, hw=1600, focal=2222.2)
-    est = Rm.StratifiedEstimator(2.0, 6.0, 128, 256)
-    out = Rm.render_rays(o, d, est, m, white_bkgd=True, device=dev)
-    (rgb, op, dep, ex), ri, tv = out
-    assert ex["weights"].shape == (96 * 384,) and ex["edges"].shape == (96, 385)
-    want = O.render_rays_oracle(o, d, sd, None, CFG["8x256"], near=2.0, far=6.0, n_samples=128, n_importance=256,
-                                white_bkgd=True, edges_override=ex["edges"].cpu())
-    close(rgb, want[0][0], rtol=0, atol=3e-2, what="bf16 rgb_map")
-    close(op, want[0][1], rtol=0, atol=3e-2, what="bf16 opacity")
-    m16 = make_model(sd, 8, 256, [4], dev, precision="fp16")
-    out16 = Rm.render_rays(o, d, est, m16, white_bkgd=True, device=dev)
-    want16 = O.render_rays_oracle(o, d, sd, None, CFG["8x256"], near=2.0, far=6.0, n_samples=128, n_importance=256,
-                                  white_bkgd=True, edges_override=out16[0][3]["edges"].cpu())
-    close(out16[0][0], want16[0][0], rtol=0, atol=5e-3, what="fp16 rgb_map")
+# (BASELINE configs[4], bf16 / fp16 single pass at 128+256: tests/test_parity_fp64.py, against the rounding-emulating oracle)
