@@ -33,7 +33,9 @@ class RenderArgs(C.Structure):
                 ("colors", C.c_void_p), ("opacity", C.c_void_p), ("depth", C.c_void_p),
                 ("weights", C.c_void_p), ("alphas", C.c_void_p), ("trans", C.c_void_p),
                 ("sigmas", C.c_void_p), ("rgbs", C.c_void_p), ("edges_out", C.c_void_p),
-                ("weights_coarse", C.c_void_p), ("status", C.c_void_p)]
+                ("weights_coarse", C.c_void_p), ("status", C.c_void_p),
+                ("cam_pose", C.c_float * 12), ("cam_H", C.c_int32), ("cam_W", C.c_int32), ("cam_row0", C.c_int32),
+                ("cam_focal", C.c_double), ("two_phase", C.c_int32)]
 
 
 _vp, _i, _i64, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double

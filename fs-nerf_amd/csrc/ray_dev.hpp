@@ -207,6 +207,25 @@ __device__ __forceinline__ void sample_pdf_merge_ray(const float* __restrict__ e
   }
 }
 
+// Pinhole ray of pixel (h, w) (src/utils/utilities.py:57-80): d_cam = [(w - W/2)/f, -(h - H/2)/f, -1], unit length,
+// rotated by the pose's 3x3 block (row-major [3][4] in m), origin = its last column.  The one definition used by
+// k_get_rays and by the fused render kernel when it generates its own rays.
+__device__ __forceinline__ void pinhole_ray(const float* __restrict__ m, float half_w, float half_h, float focal, int h,
+                                            int w, float (&o)[3], float (&d)[3]) {
+  float dx = ((float)w - half_w) / focal;
+  float dy = -((float)h - half_h) / focal;
+  float dz = -1.0f;
+  const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+  dx = dx / nrm;
+  dy = dy / nrm;
+  dz = dz / nrm;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    d[k] = (dx * m[4 * k + 0] + dy * m[4 * k + 1]) + dz * m[4 * k + 2];
+    o[k] = m[4 * k + 3];
+  }
+}
+
 // edge i of the fixed-count stratified sampler (oracle.stratified_edges)
 __device__ __forceinline__ float stratified_edge(float near, float step, int S, int i, int u_mode,
                                                  const float* __restrict__ u_ray) {

@@ -17,19 +17,12 @@ __global__ void k_get_rays(Pose34 P, int W, float half_w, float half_h, float fo
   if (p >= npix) return;
   const int h = row0 + (int)(p / W);
   const int w = (int)(p % W);
-  float dx = ((float)w - half_w) / focal;
-  float dy = -((float)h - half_h) / focal;
-  float dz = -1.0f;
-  const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
-  dx = dx / nrm;
-  dy = dy / nrm;
-  dz = dz / nrm;
-  float* d = rd + 3 * p;
-  float* o = ro + 3 * p;
+  float o[3], d[3];
+  pinhole_ray(P.m, half_w, half_h, focal, h, w, o, d);
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    d[k] = (dx * P.m[4 * k + 0] + dy * P.m[4 * k + 1]) + dz * P.m[4 * k + 2];
-    o[k] = P.m[4 * k + 3];
+    rd[3 * p + k] = d[k];
+    ro[3 * p + k] = o[k];
   }
 }
 

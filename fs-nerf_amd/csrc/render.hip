@@ -35,6 +35,8 @@ struct RenderKArgs {
   fsn_render_args a;
   int32_t G, nsubC, nsubF;
   float step;
+  int32_t two_phase;
+  float cam_hw, cam_hh, cam_f;  // W/2, H/2, focal as float32 (formed in double, utilities.py:67)
 };
 
 struct RenderLds {
@@ -43,6 +45,8 @@ struct RenderLds {
   fsn_render_args args;
   int32_t Gc, nsubC, nsubF;  // RenderKArgs::G / nsubC / nsubF / step
   float step;
+  int32_t two_phase;
+  float cam_hw, cam_hh, cam_f;
   float rays[kMaxG * 6];
   float edgesC[kMaxGroupSamples + kMaxG];
   float sigC[kMaxGroupSamples];
@@ -96,7 +100,10 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
   const fsn_render_args& a = S_.args;
   // Loop parameters are read from LDS where they are used (GRP_* below) rather than cached in registers for the
   // whole kernel: 73 fewer spilled SGPRs and 24 fewer spilled VGPRs around the MFMA passes, +2 % (A/B on MI355X).
-  if (threadIdx.x == 0) { S_.Gc = k.G; S_.nsubC = k.nsubC; S_.nsubF = k.nsubF; S_.step = k.step; }
+  if (threadIdx.x == 0) {
+    S_.Gc = k.G; S_.nsubC = k.nsubC; S_.nsubF = k.nsubF; S_.step = k.step; S_.two_phase = k.two_phase;
+    S_.cam_hw = k.cam_hw; S_.cam_hh = k.cam_hh; S_.cam_f = k.cam_f;
+  }
   __syncthreads();
   NetDev netC, netF;
   load_net(k.netF, a.pos_mask, a.dir_mask, auxF, netF);
@@ -104,19 +111,40 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
   else netC = netF;
   __syncthreads();
   WStream st;
-  st.init(smem, k.netC.blob + k.netC.stream_off, GRP_HIER ? (uint32_t)k.netC.nph_density : 0u, (uint32_t)k.nsubC,
-          k.netF.blob + k.netF.stream_off, (uint32_t)k.netF.nph_full, (uint32_t)k.nsubF);
+  {
+    // weight-stream schedule: per group "nsubC coarse tiles, nsubF fine tiles", or, in two-phase mode, all of this
+    // workgroup's coarse tiles followed by all of its fine tiles
+    const int64_t ngr = (k.a.R + k.G - 1) / k.G;
+    const int64_t mine = ngr > (int64_t)blockIdx.x ? (ngr - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const uint32_t repC = k.two_phase ? (uint32_t)(mine * k.nsubC) : (uint32_t)k.nsubC;
+    const uint32_t repF = k.two_phase ? (uint32_t)(mine * k.nsubF) : (uint32_t)k.nsubF;
+    st.init(smem, k.netC.blob + k.netC.stream_off, GRP_HIER ? (uint32_t)k.netC.nph_density : 0u, repC,
+            k.netF.blob + k.netF.stream_off, (uint32_t)k.netF.nph_full, repF);
+  }
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   ARing ring;
   prime_ring<PREC, NT>(st, ring);
-  for (int64_t grp = blockIdx.x; grp < (GRP_R + GRP_G - 1) / GRP_G; grp += gridDim.x) {
-    const int64_t r0 = grp * GRP_G;
-    // ---- rays and coarse interval edges into LDS
-    if (tid < GRP_G * 6) {
-      const int g = tid / 6, c = tid - 6 * g;
-      const int64_t ray = min(r0 + g, GRP_R - 1);
-      S_.rays[tid] = c < 3 ? a.rays_o[3 * ray + c] : a.rays_d[3 * ray + c - 3];
+  // ---- the steps of one ray group (G rays), as the kernel strings them together below
+  // rays of the group into LDS: from the caller's tensors, or generated from the camera (pose + pixel index)
+  auto load_rays = [&](int64_t r0) __attribute__((always_inline)) {
+    if (a.rays_o) {
+      if (tid < GRP_G * 6) {
+        const int g = tid / 6, c = tid - 6 * g;
+        const int64_t ray = min(r0 + g, GRP_R - 1);
+        S_.rays[tid] = c < 3 ? a.rays_o[3 * ray + c] : a.rays_d[3 * ray + c - 3];
+      }
+    } else if (tid < GRP_G) {
+      const int64_t ray = min(r0 + tid, GRP_R - 1);
+      const int h = a.cam_row0 + (int)(ray / a.cam_W), w = (int)(ray % a.cam_W);
+      float o[3], d[3];
+      pinhole_ray(a.cam_pose, S_.cam_hw, S_.cam_hh, S_.cam_f, h, w, o, d);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { S_.rays[6 * tid + c] = o[c]; S_.rays[6 * tid + 3 + c] = d[c]; }
     }
+  };
+  // stratified interval edges -> density pass of the coarse net (sigma_fn, rendering.py:58-64) -> per-ray weights,
+  // inverse-CDF resampling, sorted union (one wave per ray) -> S_.edgesF
+  auto coarse_stage = [&](int64_t r0) __attribute__((always_inline)) {
     for (int e = tid; e < GRP_G * (GRP_S + 1); e += kThreads) {
       const int g = e / (GRP_S + 1), i = e - g * (GRP_S + 1);
       const int64_t ray = min(r0 + g, GRP_R - 1);
@@ -124,35 +152,34 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
       S_.edgesC[e] = stratified_edge(a.near, S_.step, GRP_S, i, a.u_mode, ur);
     }
     lds_barrier();
-    if (GRP_HIER) {
-      // ---- density pass of the coarse net (sigma_fn, rendering.py:58-64)
-      st.pass_begin();
-      for (int sub = 0; sub < S_.nsubC; ++sub) {
-        const int idx = sub * 128 + wave * 16 + (lane & 15);
-        const int idc = min(idx, GRP_G * GRP_S - 1);
-        const int g = idc / GRP_S, i = idc - g * GRP_S;
-        const RaySrc src{S_.rays + 6 * g, S_.edgesC + g * (GRP_S + 1) + i};
-        float sigma, rgb[3];
-        mlp_tile<NT, PREC, false>(st, netC, src, ring, sigma, rgb);
-        if (lane < 16 && idx < GRP_G * GRP_S) S_.sigC[idx] = sigma;
-      }
-      st.pass_end();
-      lds_barrier();
-      // ---- per-ray weights, inverse-CDF resampling, sorted union (one wave per ray)
-      for (int g = wave; g < GRP_G; g += kWaves) {
-        const int64_t ray = min(r0 + g, GRP_R - 1);
-        float* wc = S_.wC + g * GRP_S;
-        weights_ray(S_.sigC + g * GRP_S, S_.edgesC + g * (GRP_S + 1), GRP_S, wc);
-        __builtin_amdgcn_wave_barrier();
-        if (a.weights_coarse && r0 + g < GRP_R)
-          for (int i = lane; i < GRP_S; i += 64) a.weights_coarse[ray * GRP_S + i] = wc[i];
-        sample_pdf_merge_ray(S_.edgesC + g * (GRP_S + 1), wc, GRP_S, GRP_NI, a.u_fine ? a.u_fine + ray * GRP_NI : nullptr,
-                             S_.cdf[g], S_.vals[g], S_.edgesF + g * (GRP_SO + 1));
-      }
-      lds_barrier();
+    if (!GRP_HIER) return;
+    st.pass_begin();
+    for (int sub = 0; sub < S_.nsubC; ++sub) {
+      const int idx = sub * 128 + wave * 16 + (lane & 15);
+      const int idc = min(idx, GRP_G * GRP_S - 1);
+      const int g = idc / GRP_S, i = idc - g * GRP_S;
+      const RaySrc src{S_.rays + 6 * g, S_.edgesC + g * (GRP_S + 1) + i};
+      float sigma, rgb[3];
+      mlp_tile<NT, PREC, false>(st, netC, src, ring, sigma, rgb);
+      if (lane < 16 && idx < GRP_G * GRP_S) S_.sigC[idx] = sigma;
     }
-    const float* edges = GRP_HIER ? S_.edgesF : S_.edgesC;
-    // ---- full pass of the fine net (rgb_sigma_fn, rendering.py:76-84)
+    st.pass_end();
+    lds_barrier();
+    for (int g = wave; g < GRP_G; g += kWaves) {
+      const int64_t ray = min(r0 + g, GRP_R - 1);
+      float* wc = S_.wC + g * GRP_S;
+      weights_ray(S_.sigC + g * GRP_S, S_.edgesC + g * (GRP_S + 1), GRP_S, wc);
+      __builtin_amdgcn_wave_barrier();
+      if (a.weights_coarse && r0 + g < GRP_R)
+        for (int i = lane; i < GRP_S; i += 64) a.weights_coarse[ray * GRP_S + i] = wc[i];
+      sample_pdf_merge_ray(S_.edgesC + g * (GRP_S + 1), wc, GRP_S, GRP_NI, a.u_fine ? a.u_fine + ray * GRP_NI : nullptr,
+                           S_.cdf[g], S_.vals[g], S_.edgesF + g * (GRP_SO + 1));
+    }
+    lds_barrier();
+  };
+  // full pass of the fine net (rgb_sigma_fn, rendering.py:76-84) on `edges` (LDS) -> volume integration (nerfacc
+  // rendering arithmetic, rendering.py:89-96), one wave per ray
+  auto fine_stage = [&](int64_t r0, const float* edges, bool write_edges) __attribute__((always_inline)) {
     st.pass_begin();
     for (int sub = 0; sub < S_.nsubF; ++sub) {
       const int idx = sub * 128 + wave * 16 + (lane & 15);
@@ -170,7 +197,6 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
     }
     st.pass_end();
     lds_barrier();
-    // ---- volume integration (nerfacc rendering arithmetic, rendering.py:89-96), one wave per ray
     for (int g = wave; g < GRP_G; g += kWaves) {
       if (r0 + g >= GRP_R) continue;
       const int64_t ray = r0 + g;
@@ -183,10 +209,51 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
         for (int i = lane; i < GRP_SO; i += 64) a.sigmas[ray * GRP_SO + i] = S_.sigF[g * GRP_SO + i];
       if (a.rgbs)
         for (int i = lane; i < 3 * GRP_SO; i += 64) a.rgbs[ray * GRP_SO * 3 + i] = S_.rgbF[3 * g * GRP_SO + i];
-      if (a.edges_out)
+      if (write_edges && a.edges_out)
         for (int i = lane; i <= GRP_SO; i += 64) a.edges_out[ray * (GRP_SO + 1) + i] = eg[i];
     }
     lds_barrier();
+  };
+  const int64_t ngroups = (GRP_R + GRP_G - 1) / GRP_G;
+  if (!S_.two_phase) {
+    // one group at a time: coarse pass, resampling, fine pass, integration (the weight stream alternates between
+    // the two networks; small launches, or no hand-over buffer)
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+      const int64_t r0 = grp * GRP_G;
+      load_rays(r0);
+      coarse_stage(r0);
+      fine_stage(r0, GRP_HIER ? S_.edgesF : S_.edgesC, true);
+    }
+  } else {
+    // Two phases (frame-sized hierarchical launches): coarse pass + resampling of ALL groups of this workgroup, the
+    // resampled edges handed over through a.edges_out in HBM (772 B per ray at 64+128, written and read once);
+    // then the fine pass + integration of all of them.  Every CU of an XCD now streams the same network at the
+    // same time, so the XCD's 4 MiB L2 holds one weight stream (2.0 MB coarse, then 2.3 MB fine) instead of
+    // thrashing on both; the weight stream's schedule is "coarse x all tiles, then fine x all tiles" (init below).
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+      const int64_t r0 = grp * GRP_G;
+      load_rays(r0);
+      coarse_stage(r0);
+      for (int e = tid; e < GRP_G * (GRP_SO + 1); e += kThreads) {
+        const int g = e / (GRP_SO + 1), i = e - g * (GRP_SO + 1);
+        if (r0 + g < GRP_R) a.edges_out[(r0 + g) * (GRP_SO + 1) + i] = S_.edgesF[e];
+      }
+      lds_barrier();
+    }
+    // the edges are read back by this workgroup only (same CU: the stores went through to L2, the lines were never
+    // in this CU's L1): every store issued, then a workgroup barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+      const int64_t r0 = grp * GRP_G;
+      load_rays(r0);
+      for (int e = tid; e < GRP_G * (GRP_SO + 1); e += kThreads) {
+        const int g = e / (GRP_SO + 1), i = e - g * (GRP_SO + 1);
+        S_.edgesF[e] = a.edges_out[min(r0 + g, GRP_R - 1) * (GRP_SO + 1) + i];
+      }
+      lds_barrier();
+      fine_stage(r0, S_.edgesF, false);
+    }
   }
   st.drain();
 #ifdef FSN_STAMP
@@ -248,8 +315,15 @@ extern "C" int fsn_render_rays_fused(const fsn_mlp_desc* desc, int prec, const v
   const int rc = build_geom(*desc, prec, G, &why);
   FSN_REQUIRE(rc == FSN_OK, rc, "fsn_render_rays_fused: %s", why);
   if (a.R == 0) return FSN_OK;
-  FSN_REQUIRE(blob_fine && a.rays_o && a.rays_d && a.colors && a.opacity && a.depth, FSN_E_INVALID,
-              "fsn_render_rays_fused: null pointer");
+  FSN_REQUIRE(blob_fine && a.colors && a.opacity && a.depth, FSN_E_INVALID, "fsn_render_rays_fused: null pointer");
+  if (a.rays_o) {
+    FSN_REQUIRE(a.rays_d, FSN_E_INVALID, "fsn_render_rays_fused: rays_o without rays_d");
+  } else {
+    FSN_REQUIRE(a.cam_H > 0 && a.cam_W > 0 && a.cam_focal > 0 && a.cam_row0 >= 0 &&
+                    a.R <= (int64_t)(a.cam_H - a.cam_row0) * a.cam_W,
+                FSN_E_INVALID, "fsn_render_rays_fused: no rays and no valid camera (H=%d W=%d focal=%g row0=%d R=%lld)",
+                a.cam_H, a.cam_W, a.cam_focal, a.cam_row0, (long long)a.R);
+  }
   FSN_REQUIRE(a.n_imp == 0 || blob_coarse, FSN_E_INVALID, "fsn_render_rays_fused: hierarchical sampling needs blob_coarse");
   FSN_REQUIRE(a.u_mode == 0 || a.u, FSN_E_INVALID, "fsn_render_rays_fused: u_mode %d needs u", a.u_mode);
   const int So = a.S + a.n_imp;
@@ -274,6 +348,10 @@ extern "C" int fsn_render_rays_fused(const fsn_mlp_desc* desc, int prec, const v
   k.nsubC = (g * a.S + 127) / 128;
   k.nsubF = (g * So + 127) / 128;
   k.step = (float)(((double)a.far - (double)a.near) / a.S);
+  k.two_phase = (a.two_phase && a.n_imp > 0 && a.edges_out) ? 1 : 0;
+  k.cam_hw = (float)(a.cam_W * 0.5);
+  k.cam_hh = (float)(a.cam_H * 0.5);
+  k.cam_f = (float)a.cam_focal;
   const int cus = fsn_device_cus();
   if (cus <= 0) return FSN_E_HIP;
   hipStream_t s = as_stream(stream);

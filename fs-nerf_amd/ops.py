@@ -265,21 +265,52 @@ def mlp_fwd(pm: PackedMLP, x: Tensor, dirs: Optional[Tensor] = None, pos_mask: O
     return out
 
 
-def render_fused(pm_coarse: Optional[PackedMLP], pm_fine: PackedMLP, rays_o: Tensor, rays_d: Tensor, *, near: float,
-                 far: float, n_samples: int, n_importance: int = 0, u: Optional[Tensor] = None,
+_edges_ws: Dict[Tuple[torch.device, int], Tensor] = {}
+
+
+def _edges_workspace(dev, n: int) -> Tensor:
+    """Hand-over buffer of the two-phase frame mode when the caller does not ask for the edges: one cached tensor per
+    device (grown on demand), so that a path of frames does not re-allocate 0.5 GB per frame."""
+    dev = torch.device(dev)
+    w = _edges_ws.get((dev, 0))
+    if w is None or w.numel() < n:
+        w = _edges_ws[(dev, 0)] = torch.empty(n, device=dev, dtype=torch.float32)
+    return w
+
+
+def render_fused(pm_coarse: Optional[PackedMLP], pm_fine: PackedMLP, rays_o: Optional[Tensor], rays_d: Optional[Tensor], *,
+                 near: float, far: float, n_samples: int, n_importance: int = 0, u: Optional[Tensor] = None,
                  u_fine: Optional[Tensor] = None, bkgd=(0.0, 0.0, 0.0), pos_mask: Optional[Tensor] = None,
-                 dir_mask: Optional[Tensor] = None, want_extras: bool = True):
+                 dir_mask: Optional[Tensor] = None, want_extras: bool = True, camera=None,
+                 two_phase: Optional[bool] = None):
     """One launch for the whole path (fsn_render_rays_fused).  Returns colors [R,3], opacity [R,1],
     depth [R,1], extras {weights, alphas, trans, sigmas [R,S'], rgbs [R,S',3], edges [R,S'+1],
-    weights_coarse [R,S] (hierarchical only)}."""
-    o, d = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d")
-    R = o.shape[0]
+    weights_coarse [R,S] (hierarchical only)}.
+    `camera` = (pose [3or4,4], H, W, focal, row0, nrows, device) instead of ray tensors: the rays of the image rows
+    [row0, row0+nrows) are generated inside the launch (the arithmetic of get_rays), R = nrows*W.
+    `two_phase` (default: hierarchical launches of >= 65,536 rays): all coarse passes of a workgroup before its fine
+    passes, edges handed over through HBM - one network's weight stream in L2 at a time; same results."""
     S, NI = n_samples, n_importance
     So = S + NI
-    dev = o.device
+    if camera is not None:
+        pose, cH, cW, cfocal, crow0, cnrows, dev = camera
+        dev = torch.device(dev)
+        R = int(cnrows) * int(cW)
+        o = d = None
+    else:
+        o, d = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d")
+        R = o.shape[0]
+        dev = o.device
     mode, u = _u_mode(u, R, S)
     a = L.RenderArgs()
-    a.rays_o, a.rays_d, a.R = o.data_ptr(), d.data_ptr(), R
+    a.R = R
+    if camera is None:
+        a.rays_o, a.rays_d = o.data_ptr(), d.data_ptr()
+    else:
+        pm = pose.detach().to("cpu", torch.float32)[:3, :4].contiguous().reshape(-1).tolist()
+        for i in range(12):
+            a.cam_pose[i] = pm[i]
+        a.cam_H, a.cam_W, a.cam_row0, a.cam_focal = int(cH), int(cW), int(crow0), float(cfocal)
     a.near, a.far, a.S, a.n_imp, a.u_mode = float(near), float(far), S, NI, mode
     keep = [o, d, u]
     a.u = None if u is None else u.data_ptr()
@@ -309,6 +340,13 @@ def render_fused(pm_coarse: Optional[PackedMLP], pm_fine: PackedMLP, rays_o: Ten
         if NI > 0:
             ex["weights_coarse"] = torch.empty(R, S, device=dev)
             a.weights_coarse = ex["weights_coarse"].data_ptr()
+    if two_phase is None:
+        two_phase = NI > 0 and R >= 65536
+    if two_phase and NI > 0:
+        if "edges" not in ex:
+            keep.append(_edges_workspace(dev, R * (So + 1)))
+            a.edges_out = keep[-1].data_ptr()
+        a.two_phase = 1
     if NI > 0 and pm_coarse is None:
         pm_coarse = pm_fine
     if pm_coarse is not None and pm_coarse.prec != pm_fine.prec:

@@ -117,6 +117,38 @@ def rendering(t_starts: Tensor, t_ends: Tensor, ray_indices: Tensor, n_rays: int
     return colors, opacity, depth, ex
 
 
+def _fused_launch(rays_o, rays_d, camera, estimator, model, model_fine, train, bk, u, u_fine, want_extras):
+    """ONE fused launch (ops.render_fused) for ray tensors or for a camera (rays generated in the launch), with the
+    fp16 range guard: if the kernels report activations outside the fp16 range the call is repeated in bf16x3."""
+    fine = model_fine if model_fine is not None else model
+    if camera is not None:
+        R, dev = int(camera[5]) * int(camera[2]), torch.device(camera[6])
+    else:
+        R, dev = rays_o.shape[0], rays_o.device
+    if u is None and train:
+        u = estimator.draw_u(R, dev)
+    if u_fine is None and train and estimator.n_importance > 0:
+        u_fine = torch.rand(R, estimator.n_importance, device=dev, generator=estimator.generator)
+    near, far = estimator.bounds()
+    pm = fine._mask(fine.pos_mask, dev)
+    dm = fine._mask(fine.dir_mask, dev)
+
+    def launch():
+        return ops.render_fused(
+            model.packed() if estimator.n_importance > 0 else None, fine.packed(), rays_o, rays_d,
+            near=near, far=far, n_samples=estimator.n_samples, n_importance=estimator.n_importance,
+            u=u, u_fine=u_fine, bkgd=(bk, bk, bk), pos_mask=pm, dir_mask=dm, want_extras=want_extras, camera=camera)
+
+    out = launch()
+    nets = [m for m in {id(model): model, id(fine): fine}.values()]
+    if any(m.range_check and m.fp16_family(m.PRECISIONS[m.precision]) for m in nets) and not ops.range_ok(dev):
+        for m in nets:  # the coarse and the fine pass run in one precision mode
+            if m.fp16_family(m.PRECISIONS[m.precision]):
+                m.fall_back("render_rays")
+        out = launch()
+    return out
+
+
 def render_rays(rays_o: Tensor, rays_d: Tensor, estimator, model: nn.Module, train: bool = False,
                 white_bkgd: bool = False, render_step_size: float = 5e-3,
                 device: torch.device = torch.device("cuda"), *, model_fine: Optional[nn.Module] = None,
@@ -136,29 +168,8 @@ def render_rays(rays_o: Tensor, rays_d: Tensor, estimator, model: nn.Module, tra
     fused = isinstance(estimator, StratifiedEstimator) and isinstance(model, NeRF) and \
         (model_fine is None or isinstance(model_fine, NeRF)) and not needs_grad
     if fused:
-        R = rays_o.shape[0]
-        fine = model_fine if model_fine is not None else model
-        if u is None and train:
-            u = estimator.draw_u(R, rays_o.device)
-        if u_fine is None and train and estimator.n_importance > 0:
-            u_fine = torch.rand(R, estimator.n_importance, device=rays_o.device, generator=estimator.generator)
-        near, far = estimator.bounds()
-        pm = fine._mask(fine.pos_mask, rays_o.device)
-        dm = fine._mask(fine.dir_mask, rays_o.device)
-        def launch():
-            return ops.render_fused(
-                model.packed() if estimator.n_importance > 0 else None, fine.packed(), rays_o, rays_d,
-                near=near, far=far, n_samples=estimator.n_samples, n_importance=estimator.n_importance,
-                u=u, u_fine=u_fine, bkgd=(bk, bk, bk), pos_mask=pm, dir_mask=dm, want_extras=want_extras)
-
-        rgb, opacity, depth, ex = launch()
-        nets = [m for m in {id(model): model, id(fine): fine}.values()]
-        if any(m.range_check and m.fp16_family(m.PRECISIONS[m.precision]) for m in nets) and \
-                not ops.range_ok(rays_o.device):
-            for m in nets:  # the coarse and the fine pass run in one precision mode
-                if m.fp16_family(m.PRECISIONS[m.precision]):
-                    m.fall_back("render_rays")
-            rgb, opacity, depth, ex = launch()
+        rgb, opacity, depth, ex = _fused_launch(rays_o, rays_d, None, estimator, model, model_fine, train, bk, u, u_fine,
+                                                want_extras)
         if not want_extras:  # frame rendering: only rgb / depth are consumed (rendering.py:169-171)
             return (rgb, opacity, depth, ex), None, None
         edges = ex["edges"]
@@ -203,17 +214,26 @@ def render_frame(hwf: Tuple[int, int, float], near: float, far: float, pose: Ten
     (rendering.py:146-177).  Deliberate difference: the reference passes `white_bkgd` positionally
     into render_rays' `train` slot (rendering.py:160-168), so its frames are always composited on
     black; here `train` and `white_bkgd` go to the parameters they name."""
-    H, W, _ = hwf
+    H, W, focal = hwf
+    fine = model_fine if model_fine is not None else model
+    fused = isinstance(estimator, StratifiedEstimator) and isinstance(model, NeRF) and isinstance(fine, NeRF) and \
+        not (torch.is_grad_enabled() and fine.training)
+    if fused and not ndc:
+        # SURVEY 8f row f3: ONE persistent launch per frame - the rays are generated inside it from (pose, pixel
+        # index), nothing per sample or per ray is kept in HBM besides the image, so `chunksize` (the reference's
+        # memory knob: 313 launches for an 800x800 frame at 2048) is not needed.  Rays are independent: the image is
+        # the chunked one.
+        dev = torch.device(device)
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        rgb, _, depth, _ = _fused_launch(None, None, (pose, H, W, focal, 0, H, dev), estimator, model, model_fine,
+                                         train, float(white_bkgd), None, None, False)
+        return rgb.reshape(H, W, 3), depth.clamp(near, far).reshape(H, W)
     rays_o, rays_d = U.get_rays(pose, hwf, device)
     rays_o, rays_d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
     if ndc:
         rays_o, rays_d = U.to_ndc(rays_o, rays_d, hwf, 1.0)
-    fine = model_fine if model_fine is not None else model
-    if isinstance(estimator, StratifiedEstimator) and isinstance(model, NeRF) and isinstance(fine, NeRF) and \
-            not (torch.is_grad_enabled() and fine.training):
-        # SURVEY 8f row f3: the fused kernel keeps nothing per sample in HBM, so `chunksize` (the reference's memory
-        # knob, 313 launches for an 800x800 frame at 2048) is not needed: ONE persistent launch per frame.  Rays are
-        # independent, so the image is the same as the chunked one.
+    if fused:  # (NDC frames: rays through to_ndc, then one fused launch)
         chunksize = max(int(rays_o.shape[0]), 1)
     img, depth_map = [], []
     for co, cd in zip(U.get_chunks(rays_o, chunksize), U.get_chunks(rays_d, chunksize)):

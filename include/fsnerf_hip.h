@@ -140,6 +140,7 @@ int fsn_mlp_fwd(const fsn_mlp_desc* desc, int prec, const void* blob, const floa
  * the fine net -> volume integration.  n_imp == 0 renders the S coarse intervals with
  * `blob_fine` only (blob_coarse unused).  S_out = S + n_imp intervals per ray.
  *   u_mode/u as fsn_stratified_edges; u_fine [R,n_imp] or NULL (deterministic).
+ *   rays_o / rays_d [R,3], or rays_o == NULL and the cam_* fields (rays generated in the launch);
  *   outputs: colors [R,3], opacity [R], depth [R]; optional (NULL to skip):
  *   weights, alphas, trans, sigmas [R,S_out], rgbs [R,S_out,3], edges_out [R,S_out+1],
  *   weights_coarse [R,S] (only written when n_imp > 0). */
@@ -166,6 +167,18 @@ typedef struct fsn_render_args {
   float* edges_out;
   float* weights_coarse;
   uint32_t* status; /* range guard of the fp16 modes (above), or NULL */
+  /* f3: rays generated inside the launch.  When rays_o == NULL (rays_d ignored), ray r is pixel
+   * (cam_row0 + r / cam_W, r % cam_W) of the cam_H x cam_W pinhole image of `cam_pose` (12 floats, rows 0..2 of the
+   * camera-to-world matrix) with focal length cam_focal: the arithmetic of fsn_get_rays (utilities.py:57-80),
+   * so a frame is ONE launch with no ray tensors in HBM.  R = number of pixels rendered. */
+  float cam_pose[12];
+  int32_t cam_H, cam_W, cam_row0;
+  double cam_focal;
+  /* Hierarchical launches over many rays run in two phases when `edges_out` is given (it doubles as the hand-over
+   * buffer): every workgroup first runs the coarse pass + resampling of ALL its ray groups, then the fine pass of
+   * all of them, so that an XCD's L2 holds ONE network's weight stream at a time (2.0 / 2.3 MB of the 4 MiB)
+   * instead of both.  Results are identical.  two_phase: 0 = never, 1 = whenever edges_out != NULL and n_imp > 0. */
+  int32_t two_phase;
 } fsn_render_args;
 
 int fsn_render_rays_fused(const fsn_mlp_desc* desc, int prec, const void* blob_coarse,

@@ -18,6 +18,8 @@ from fs_nerf_amd import _lib, ops  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--prec", default="fp16x3")
 ap.add_argument("--rounds", type=int, default=3)
+ap.add_argument("--two-phase", type=int, default=1)
+ap.add_argument("--camera", type=int, default=1)
 ap.add_argument("libs", nargs="+")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -42,8 +44,10 @@ default = _lib._lib
 def run(l):
     _lib._lib = l
     try:
-        return ops.render_fused(pc, pf, o, d, near=2.0, far=6.0, n_samples=64, n_importance=128, bkgd=(1, 1, 1),
-                                want_extras=False)
+        cam = (bench.orbit_pose(0.0), bench.H, bench.W, bench.FOCAL, 0, bench.H, dev) if args.camera else None
+        return ops.render_fused(pc, pf, None if cam else o, None if cam else d, near=2.0, far=6.0, n_samples=64,
+                                n_importance=128, bkgd=(1, 1, 1), want_extras=False, camera=cam,
+                                two_phase=bool(args.two_phase))
     finally:
         _lib._lib = default
 
