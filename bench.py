@@ -144,7 +144,8 @@ def train_main(args, rank, world, dev, dist, backend):
     model.to(dev).train()
     est = Rm.StratifiedEstimator(0.0, 1.0, S, NI).train()  # NDC: near 0, far 1 (llff.py:51-53)
     est.generator = torch.Generator(device=dev).manual_seed(1000 + rank)
-    opt = torch.optim.Adam(model.parameters(), lr=5e-4, fused=os.environ.get("FSN_FUSED_ADAM", "1") == "1")
+    from fs_nerf_amd.core.optim import FusedAdam
+    opt = FusedAdam(model.parameters(), lr=5e-4)  # one launch over the flat parameter / gradient arenas
     sched = ExponentialDecay(opt, 10000, 5e-4, r=0.1)
     ro, rd, _ = U.build_rays(train_poses(), (T_H, T_W, T_FOCAL), dev, ndc=True)  # dataset precompute (llff.py:59-90)
     gt = torch.rand(ro.shape[0], 3, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
@@ -152,12 +153,12 @@ def train_main(args, rank, world, dev, dist, backend):
 
     def step():
         idx = torch.randint(0, ro.shape[0], (T_RAYS,), device=dev, generator=gen)
-        opt.zero_grad(set_to_none=True)
+        opt.zero_grad()  # one fill of the flat gradient bucket; every p.grad is a view into it
         (rgb, _, _, _), _, _ = Rm.render_rays(ro[idx], rd[idx], est, model, train=True, white_bkgd=True, device=dev)
         loss = torch.nn.functional.mse_loss(rgb, gt[idx])
         loss.backward()
-        shard.allreduce_grads(model.parameters())
-        opt.step()
+        opt.grads.allreduce(average=False)  # ONE RCCL all-reduce (sum) of the bucket; nothing else crosses GPUs
+        opt.step(grad_div=float(world))     # ... the 1/world of the mean is folded into the Adam launch
         sched.step()
         return loss.detach()
 
@@ -376,7 +377,7 @@ def main():
         rgb, op, depth, _ = ops.render_fused(pc, pf, None, None, near=NEAR, far=FAR, n_samples=S, n_importance=NI,
                                              bkgd=(1.0, 1.0, 1.0), want_extras=False,
                                              camera=(pose, H, W, FOCAL, 0, H, dev),
-                                             two_phase=os.environ.get("FSN_TWO_PHASE", "1") == "1")
+                                             two_phase=os.environ.get("FSN_TWO_PHASE", "0") == "1")
         e1.record()
         if timed:
             ev.append((e0, e1))

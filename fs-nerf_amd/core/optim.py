@@ -1,0 +1,101 @@
+"""Optimizer side of the training step on the device (reference: `torch.optim.Adam(params, lr)` at
+src/run-nerf.py:217, `optimizer.step()` / `zero_grad()` at :283-285).
+
+`FlatParams` re-homes every parameter of a model into ONE flat float32 arena (each `p.data` becomes a view), with the
+gradients in a second arena of the same layout (`shard.FlatGrads`: the buffer the RCCL all-reduce runs on).
+`FusedAdam` is a `torch.optim.Optimizer` whose `step()` is a single HIP launch over those arenas
+(`fsn_adam_step`, torch.optim.Adam's arithmetic operation for operation) - no per-tensor kernels, no `torch.cat`."""
+from typing import Iterable, List, Optional
+
+import torch
+from torch import Tensor
+
+from .. import _lib as L
+from .. import ops
+from ..shard import FlatGrads
+
+
+class FlatParams:
+    """All trainable parameters as views into one contiguous float32 buffer (state_dict keys and shapes unchanged)."""
+
+    def __init__(self, params: Iterable[Tensor]):
+        self.params: List[Tensor] = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatParams: no trainable parameters")
+        dev = self.params[0].device
+        if not all(p.is_cuda and p.device == dev and p.dtype == torch.float32 for p in self.params):
+            raise RuntimeError("FlatParams: float32 parameters on one GPU expected (the HIP path has no CPU fallback)")
+        self.offsets, n = [], 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += p.numel()
+        self.numel = n
+        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, off in zip(self.params, self.offsets):
+                v = self.flat[off:off + p.numel()].view_as(p)
+                v.copy_(p.data)
+                p.data = v
+        self.grads = FlatGrads(self.params)
+
+    def offset_of(self, p: Tensor) -> int:
+        for q, off in zip(self.params, self.offsets):
+            if q is p:
+                return off
+        raise KeyError("parameter is not part of this arena")
+
+    def attached(self) -> bool:
+        """False once something (e.g. `model.to(...)`, `load_state_dict(assign=True)`) replaced a parameter's storage."""
+        base = self.flat.data_ptr()
+        return all(p.data_ptr() == base + 4 * off for p, off in zip(self.params, self.offsets))
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """`torch.optim.Adam(params, lr=..., betas=..., eps=..., weight_decay=...)` (no amsgrad) as one launch per step.
+    `grad_div`: see `step`.  The parameters are moved into a `FlatParams` arena on construction."""
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+        params = list(params)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        if len(self.param_groups) != 1:
+            raise ValueError("FusedAdam: one parameter group (the reference uses one, run-nerf.py:216-217)")
+        self.arena = FlatParams(self.param_groups[0]["params"])
+        self.exp_avg = torch.zeros_like(self.arena.flat)
+        self.exp_avg_sq = torch.zeros_like(self.arena.flat)
+        self.steps = 0
+
+    @property
+    def grads(self) -> FlatGrads:
+        return self.arena.grads
+
+    def zero_grad(self, set_to_none: bool = False) -> None:  # one fill of the gradient arena
+        self.arena.grads.zero()
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_div: float = 1.0):
+        """`grad_div` = world size when the gradient arena holds an all-reduced SUM (`FlatGrads.allreduce(average=
+        False)`): the division of the data-parallel mean then costs no pass of its own."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if not self.arena.attached():
+            raise RuntimeError("FusedAdam: a parameter no longer lives in the optimizer's arena (was the model moved or "
+                               "re-assigned after the optimizer was built?)")
+        g = self.param_groups[0]
+        self.arena.grads.bind()
+        self.steps += 1
+        a = self.arena
+        with torch.cuda.device(a.flat.device):
+            L.check(L.lib().fsn_adam_step(ops._p(a.flat), ops._p(a.grads.flat), ops._p(self.exp_avg),
+                                          ops._p(self.exp_avg_sq), a.numel, self.steps, float(g["lr"]),
+                                          float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                          float(g["weight_decay"]), float(grad_div), ops._stream()), "fsn_adam_step")
+        self._bump_versions()
+        return loss
+
+    def _bump_versions(self) -> None:
+        # `NeRF.packed()` re-packs when a parameter's version counter changed; the HIP launch wrote through raw
+        # pointers, so the write is recorded here (no kernel: the counter only).
+        for p in self.arena.params:
+            torch.autograd.graph.increment_version(p)

@@ -375,3 +375,61 @@ extern "C" int fsn_to8b(const float* x, int64_t n, uint8_t* out, fsn_stream_t st
   FSN_LAUNCH_CHECK("k_to8b");
   return FSN_OK;
 }
+
+namespace fsn {
+// ---------------------------------------------------------------- f3: video tensors (rendering.py:240-266)
+// frames [N,HW,3] float -> uint8 [N,3,HW] = transpose(to8b(frames), (0,3,1,2)); one thread per output byte
+// (coalesced byte stores, 12-byte-strided reads served by L2).
+__global__ void k_to8b_nchw(const float* __restrict__ x, int64_t n_frames, int64_t hw, uint8_t* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_frames * 3 * hw) return;
+  const int64_t f = e / (3 * hw), r = e - f * 3 * hw;
+  const int64_t c = r / hw, p = r - c * hw;
+  const float v = x[(f * hw + p) * 3 + c];
+  out[e] = (uint8_t)(255.0f * fminf(fmaxf(v, 0.0f), 1.0f));
+}
+
+// depth [N,HW] -> colours [N,3,HW]: matplotlib's Normalize(vmin, vmax) in float32 followed by the colormap's
+// lookup (index = int(x * 256), x == 1 -> 255, below / above range -> first / last entry) in a 256-entry table that
+// already holds to8b() of the colormap's RGB (uint8 [256][3]).  vmm = {vmin, vmax} on the device.
+__global__ void k_depth_colormap(const float* __restrict__ d, int64_t n_frames, int64_t hw, const float* __restrict__ vmm,
+                                 const uint8_t* __restrict__ lut, uint8_t* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_frames * hw) return;
+  const int64_t f = e / hw, p = e - f * hw;
+  const float vmin = vmm[0], vmax = vmm[1];
+  float x = 0.0f;
+  if (vmin != vmax) x = (d[e] - vmin) / (vmax - vmin);
+  float xa = x * 256.0f;
+  if (xa == 256.0f) xa = 255.0f;
+  int idx = xa < 0.0f ? 0 : (xa >= 256.0f ? 255 : (int)xa);
+  if (!(xa == xa)) idx = 0;  // NaN depth: matplotlib's "bad" colour is transparent black; RGB of entry 0 is kept here
+  uint8_t* o = out + f * 3 * hw + p;
+  o[0] = lut[3 * idx + 0];
+  o[hw] = lut[3 * idx + 1];
+  o[2 * hw] = lut[3 * idx + 2];
+}
+
+}  // namespace fsn
+
+using namespace fsn;
+
+extern "C" int fsn_to8b_nchw(const float* frames, int64_t n_frames, int64_t hw, uint8_t* out, fsn_stream_t stream) {
+  FSN_REQUIRE(n_frames >= 0 && hw >= 0, FSN_E_INVALID, "fsn_to8b_nchw: negative size");
+  const int64_t n = n_frames * 3 * hw;
+  if (n == 0) return FSN_OK;
+  FSN_REQUIRE(frames && out, FSN_E_INVALID, "fsn_to8b_nchw: null pointer");
+  k_to8b_nchw<<<nblocks(n, 256), 256, 0, as_stream(stream)>>>(frames, n_frames, hw, out);
+  FSN_LAUNCH_CHECK("k_to8b_nchw");
+  return FSN_OK;
+}
+
+extern "C" int fsn_depth_colormap(const float* depth, int64_t n_frames, int64_t hw, const float* vmin_vmax,
+                                  const uint8_t* lut_rgb8, uint8_t* out, fsn_stream_t stream) {
+  FSN_REQUIRE(n_frames >= 0 && hw >= 0, FSN_E_INVALID, "fsn_depth_colormap: negative size");
+  if (n_frames * hw == 0) return FSN_OK;
+  FSN_REQUIRE(depth && vmin_vmax && lut_rgb8 && out, FSN_E_INVALID, "fsn_depth_colormap: null pointer");
+  k_depth_colormap<<<nblocks(n_frames * hw, 256), 256, 0, as_stream(stream)>>>(depth, n_frames, hw, vmin_vmax, lut_rgb8, out);
+  FSN_LAUNCH_CHECK("k_depth_colormap");
+  return FSN_OK;
+}

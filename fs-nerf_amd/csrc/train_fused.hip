@@ -24,8 +24,10 @@
 // x3 modes: pinned one-unit-ahead LDS prefetch of the A operands (mlp_dev.hpp).  +6 % on these kernels; the fused
 // render kernel keeps the compiler's own read placement (with its larger live state the pinned form spills more).
 #define FSN_X3_PF1
+// wgrad converts its operands with the compiler-scheduled C++ split: the inline-asm form (mlp_dev.hpp) cannot be
+// interleaved with the global loads and cost 30 % there (k_wgrad<4,4,2>: 4.37 ms against 3.36 ms per step)
 #ifndef FSN_WG_SPLIT
-#define FSN_WG_SPLIT split_store
+#define FSN_WG_SPLIT split_store_cpp
 #endif
 #include "mlp_dev.hpp"
 #include "mlp_layout.hpp"
@@ -580,12 +582,17 @@ struct RdJob {
 struct RdArgs {
   RdJob job[2 * kMaxLayers + 4];
   const float* scale;
+  const uint32_t* status;  // fp16 range guard: when raised, this step's gradients are written as zeros
 };
 
 __global__ void k_wgrad_reduce(RdArgs a) {
   const RdJob jb = a.job[blockIdx.y];
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const float inv = a.scale ? 1.0f / a.scale[0] : 1.0f;
+  // A forward / backward launch of this step reported values outside the fp16 range (status bit 0): the sums are
+  // inf / NaN.  Like a loss scaler's skipped step the gradients are zeroed ON THE DEVICE, without a host sync; the
+  // host learns of it at its next (amortised) look at the status word and continues in bf16x3.
+  const bool skip = a.status && (a.status[0] & 1u);
   const int tot = jb.a_rows * jb.b_rows;
   if (e < tot) {
     const int row = e / jb.b_rows, c = e - row * jb.b_rows;
@@ -601,13 +608,13 @@ __global__ void k_wgrad_reduce(RdArgs a) {
     if (colo >= 0) {
       float sum = 0.f;
       for (int p = 0; p < jb.nsplit; ++p) sum += jb.part[(int64_t)p * tot + e];
-      jb.dW[(int64_t)row * jb.ld + colo] = sum * inv;
+      jb.dW[(int64_t)row * jb.ld + colo] = skip ? 0.f : sum * inv;
     }
   }
   if (jb.bpart && e < jb.a_rows) {
     float sum = 0.f;
     for (int p = 0; p < jb.nsplit; ++p) sum += jb.bpart[(int64_t)p * jb.a_rows + e];
-    jb.db[e] = sum * inv;
+    jb.db[e] = skip ? 0.f : sum * inv;
   }
 }
 
@@ -685,6 +692,7 @@ struct HeadsRdArgs {
   int32_t nsplit, D;
   const float* scale;
   float *dWs, *dbs, *dWr, *dbr;
+  const uint32_t* status;  // as in RdArgs
 };
 __global__ void k_heads_reduce(HeadsRdArgs a) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -694,6 +702,7 @@ __global__ void k_heads_reduce(HeadsRdArgs a) {
   float sum = 0.f;
   for (int p = 0; p < a.nsplit; ++p) sum += a.hpart[(int64_t)p * n + e];
   sum *= inv;
+  if (a.status && (a.status[0] & 1u)) sum = 0.f;
   if (e < a.D) a.dWs[e] = sum;
   else if (e < a.D + 3 * (a.D / 2)) a.dWr[e - a.D] = sum;
   else if (e < n - 1) a.dbr[e - a.D - 3 * (a.D / 2)] = sum;
@@ -868,6 +877,7 @@ int fused_train_bwd(const fsn_mlp_desc* d, int prec, const float* const* W, int6
     if ((rc = launch_wgrad<1, 1>(prec, bd, nbd, s)) != FSN_OK) return rc;
   }
   rd.scale = grad_scale_dev;
+  rd.status = status;
   {
     dim3 grid((unsigned)((D * D + 255) / 256), (unsigned)nrd);
     k_wgrad_reduce<<<grid, 256, 0, s>>>(rd);
@@ -879,7 +889,7 @@ int fused_train_bwd(const fsn_mlp_desc* d, int prec, const float* const* W, int6
     if (D == 256) k_heads_wgrad<8><<<(unsigned)F.nsplit_heads, kThreads, 0, s>>>(ha);
     else k_heads_wgrad<4><<<(unsigned)F.nsplit_heads, kThreads, 0, s>>>(ha);
     FSN_LAUNCH_CHECK("k_heads_wgrad");
-    HeadsRdArgs hr{ws + F.hpart, F.nsplit_heads, D, grad_scale_dev, dW[L], db[L], dW[L + 3], db[L + 3]};
+    HeadsRdArgs hr{ws + F.hpart, F.nsplit_heads, D, grad_scale_dev, dW[L], db[L], dW[L + 3], db[L + 3], status};
     const int nn = D + 3 * (D / 2) + 4;
     k_heads_reduce<<<(unsigned)((nn + 255) / 256), 256, 0, s>>>(hr);
     FSN_LAUNCH_CHECK("k_heads_reduce");

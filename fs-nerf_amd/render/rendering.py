@@ -271,3 +271,16 @@ def render_path(render_poses: Tensor, hwf: Tuple[int, int, float], near: float, 
         frames.append(rgb.reshape(H, W, 3).detach().cpu().numpy())
         d_frames.append(depth.reshape(H, W).detach().cpu().numpy())
     return np.stack(frames, 0), np.stack(d_frames, 0)
+
+
+def render_video(frames, d_frames, cmap: str = "plasma"):
+    """Video tensors (rendering.py:240-266): (uint8 [N,3,H,W] colour frames, uint8 [N,3,H,W] colormapped depth frames),
+    depth normalised with the minimum / maximum over ALL frames.  The whole assembly (to8b, NHWC -> NCHW, Normalize,
+    colormap lookup) runs on the GPU; numpy inputs (what `render_path` returns, like the reference's) are uploaded
+    once and numpy arrays are returned, tensors in -> tensors out."""
+    as_np = not isinstance(frames, Tensor)
+    dev = torch.device("cuda", torch.cuda.current_device()) if as_np else frames.device
+    fr = torch.as_tensor(np.ascontiguousarray(frames), dtype=torch.float32).to(dev) if as_np else frames
+    dp = torch.as_tensor(np.ascontiguousarray(d_frames), dtype=torch.float32).to(dev) if as_np else d_frames.to(dev)
+    f8, d8 = ops.video_tensors(fr, dp, cmap)
+    return (f8.cpu().numpy(), d8.cpu().numpy()) if as_np else (f8, d8)

@@ -203,17 +203,14 @@ int fsn_occlusion_reg_bwd(const float* t_vals, int64_t N, const float* ray_sums,
 /* f1: the training step around the path.                         src/run-nerf.py:243-285, models.py:111-143
  * NeRF.forward keeping what its backward needs in a caller-provided workspace, and that backward (gradients of
  * every parameter; sample positions / directions receive none on this path).
- *   prec 0..3 (FSN_PREC_*): the MFMA path.  Forward = the inference kernel with fp32 activations saved in tiles of
+ *   prec 0..3 (FSN_PREC_*).  Forward = the inference kernel with fp32 activations saved in tiles of
  *     128 samples; backward = register-resident dgrad chain on transposed weights + split-K wgrad GEMMs over all
  *     samples (csrc/train_fused.hip).  grad_scale: DEVICE pointer to one float, a power of two that d_out is
  *     multiplied by on entry (results are divided by it again) so that fp16 parts keep small gradients; null = 1.
- *   prec FSN_PREC_FP32: the plain formulation, fp32 library GEMMs (rocBLAS sgemm, bound with dlopen at first
- *     use) layer by layer; the reference the MFMA path is tested against.  grad_scale must be null.
  *   weights / biases / d_weights / d_biases: HOST arrays of n_layers+4 DEVICE pointers in state_dict order
  *   (layers.0.., sigma, connection, branch, rgb); gradients are overwritten, not accumulated.
  *   workspace: fsn_nerf_train_workspace_floats(desc, prec, n) floats, written by _fwd, consumed (and scribbled on)
  *   by _bwd with the same desc / prec / n; out / d_out [n,4] = [rgb, sigma]. */
-#define FSN_PREC_FP32 4
 int64_t fsn_nerf_train_workspace_floats(const fsn_mlp_desc* desc, int prec, int64_t n);
 int fsn_nerf_train_fwd(const fsn_mlp_desc* desc, int prec, const float* const* weights, const float* const* biases,
                        const float* x, const float* dirs, const float* pos_mask, const float* dir_mask,
@@ -227,6 +224,24 @@ int fsn_composite_packed_bwd(const float* sigmas, const float* rgbs, const float
                              const int64_t* ray_indices, int64_t N, int64_t R, const float* bkgd_host,
                              const float* d_colors, const float* d_opacity, float* d_sigmas, float* d_rgbs,
                              fsn_stream_t stream);
+
+/* f1: optimizer side of the training step on ONE flat float32 parameter arena (run-nerf.py:217, 266-285).
+ * fsn_adam_step: torch.optim.Adam's update (no amsgrad), operation for operation in float32, one launch over the
+ *   arena: params / grads / exp_avg / exp_avg_sq [n]; `step` = 1, 2, ... (bias corrections are formed in double on
+ *   the host); grad_div divides the gradient first (pass the number of ranks when `grads` holds an all-reduced SUM).
+ * fsn_weight_norm_*: the weight-norm "frequency" regulariser of run-nerf.py:266-279: out = sum over the selected
+ *   tensors (segments [off, off+len) of the arena, HOST tables, <= 40) of |w|_1 (l2 = 0) or |w|_2 (l2 = 1).
+ *   workspace: fsn_weight_norm_workspace_floats(...) floats, written by _fwd and read by _bwd (per-tensor norms);
+ *   _bwd ACCUMULATES d_out[0] * d(out)/dw into grad_arena (same layout as the arena).  No atomics: sums are taken
+ *   in a fixed order. */
+int fsn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int step,
+                  double lr, double beta1, double beta2, double eps, double weight_decay, double grad_div,
+                  fsn_stream_t stream);
+int64_t fsn_weight_norm_workspace_floats(int n_seg, const int64_t* seg_len_host);
+int fsn_weight_norm_fwd(const float* arena, int n_seg, const int64_t* seg_off_host, const int64_t* seg_len_host, int l2,
+                        float* workspace, float* out, fsn_stream_t stream);
+int fsn_weight_norm_bwd(const float* arena, int n_seg, const int64_t* seg_off_host, const int64_t* seg_len_host, int l2,
+                        const float* workspace, const float* d_out, float* grad_arena, fsn_stream_t stream);
 
 /* f2: occupancy-grid sampler for the `estimator` slot (nerfacc OccGridEstimator; call sites
  * src/render/rendering.py:66-74, src/run-nerf.py:96-98, 288-295).  nerfacc is not part of the reference: the
@@ -254,6 +269,14 @@ int fsn_occgrid_update(float* occs, int64_t n_cells, const int64_t* cells, const
 
 /* f3: to8b(x) = (255 * clip(x, 0, 1)).astype(uint8)                    src/render/rendering.py:21 */
 int fsn_to8b(const float* x, int64_t n, uint8_t* out, fsn_stream_t stream);
+/* f3: render_video(frames, d_frames, cmap)                             src/render/rendering.py:240-266
+ * fsn_to8b_nchw: frames [N,HW,3] float -> uint8 [N,3,HW] = transpose(to8b(frames), (0,3,1,2)).
+ * fsn_depth_colormap: depth [N,HW] -> uint8 [N,3,HW]: matplotlib's Normalize(vmin, vmax) (float32; vmin == vmax
+ *   maps to 0) and ScalarMappable lookup, index = int(x * 256) (x == 1 -> 255, out of range -> first / last entry),
+ *   in lut_rgb8 = to8b of the colormap's 256 RGB entries (uint8 [256][3], device).  vmin_vmax: 2 floats (device). */
+int fsn_to8b_nchw(const float* frames, int64_t n_frames, int64_t hw, uint8_t* out, fsn_stream_t stream);
+int fsn_depth_colormap(const float* depth, int64_t n_frames, int64_t hw, const float* vmin_vmax,
+                       const uint8_t* lut_rgb8, uint8_t* out, fsn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -137,5 +137,39 @@ def main():
     print("golden vectors written to", HERE)
 
 
+
+
+def make_g6_video():
+    """render_video (src/render/rendering.py:240-266).  `render.rendering` itself cannot be imported here (imageio and
+    nerfacc are missing), so its body - six matplotlib / numpy calls - is evaluated with the same calls:
+    Normalize over all frames, ScalarMappable(cmap).to_rgba on the flattened depths, to8b, NHWC -> NCHW."""
+    import matplotlib
+    from matplotlib import cm
+    rng = np.random.default_rng(6)
+    frames = rng.uniform(-0.2, 1.2, size=(2, 5, 7, 3)).astype(np.float32)   # values outside [0,1] exercise the clip
+    d_frames = rng.uniform(2.0, 6.0, size=(2, 5, 7)).astype(np.float32)
+    d_frames[0, 0, 0], d_frames[1, 4, 6] = 2.0, 6.0
+    to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)
+    out = {"frames": frames, "d_frames": d_frames}
+    for cmap in ("plasma", "viridis"):
+        norm = matplotlib.colors.Normalize(vmin=np.amin(d_frames), vmax=np.amax(d_frames))
+        mapper = cm.ScalarMappable(norm=norm, cmap=cmap)
+        d_rgba = mapper.to_rgba(d_frames.flatten())
+        d_rgba = np.reshape(d_rgba, list(d_frames.shape[:3]) + [-1])
+        out[f"{cmap}_frames8"] = np.transpose(to8b(frames), (0, 3, 1, 2))
+        out[f"{cmap}_depth8"] = np.transpose(to8b(d_rgba[..., :3]), (0, 3, 1, 2))
+    # a constant depth map: vmin == vmax -> everything maps to the first entry
+    flat = np.full((1, 3, 4), 3.5, np.float32)
+    norm = matplotlib.colors.Normalize(vmin=np.amin(flat), vmax=np.amax(flat))
+    out["flat_d"] = flat
+    out["flat_depth8"] = np.transpose(to8b(np.reshape(cm.ScalarMappable(norm=norm, cmap="plasma").to_rgba(flat.flatten()),
+                                                      [1, 3, 4, -1])[..., :3]), (0, 3, 1, 2))
+    np.savez_compressed(os.path.join(HERE, "g6_video.npz"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if "--video" in sys.argv:  # only the video fixture (needs matplotlib, not the reference)
+        make_g6_video()
+    else:
+        main()
+        make_g6_video()

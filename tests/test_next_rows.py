@@ -119,3 +119,35 @@ def test_occlusion_regularizer_gradient(func):
     (want * 2.5).backward()
     assert abs(float(out) - float(want)) < 1e-5 * max(1.0, abs(float(want)))
     assert torch.allclose(s_gpu.grad.cpu().double(), s64.grad, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cmap", ["plasma", "viridis"])
+def test_render_video_matches_matplotlib_golden(golden_dir, cmap):
+    """f3: depth colormap + to8b + NHWC->NCHW on the device against the reference's own lines evaluated with
+    matplotlib (tests/golden/make_golden.py::make_g6_video), byte for byte."""
+    from fs_nerf_amd.render import rendering as Rm
+    g = np.load(os.path.join(golden_dir, "g6_video.npz"))
+    f8, d8 = Rm.render_video(g["frames"], g["d_frames"], cmap)  # numpy in (what render_path returns) -> numpy out
+    assert f8.dtype == np.uint8 and f8.shape == (2, 3, 5, 7) and d8.shape == (2, 3, 5, 7)
+    assert np.array_equal(f8, g[f"{cmap}_frames8"])
+    assert np.array_equal(d8, g[f"{cmap}_depth8"])
+    dev = torch.device("cuda:0")
+    tf, td = Rm.render_video(torch.from_numpy(g["frames"]).to(dev), torch.from_numpy(g["d_frames"]).to(dev), cmap)
+    assert tf.is_cuda and np.array_equal(td.cpu().numpy(), g[f"{cmap}_depth8"])
+    if cmap == "plasma":  # constant depth: vmin == vmax
+        _, fl = Rm.render_video(np.zeros((1, 3, 4, 3), np.float32), g["flat_d"], "plasma")
+        assert np.array_equal(fl, g["flat_depth8"])
+    with pytest.raises(ValueError):
+        Rm.render_video(g["frames"], g["d_frames"], "no-such-map")
+
+
+def test_colormap_tables_are_matplotlibs():
+    """The shipped uint8 tables equal to8b of matplotlib's colormaps (when matplotlib is importable)."""
+    mpl = pytest.importorskip("matplotlib")
+    from fs_nerf_amd.render.cmaps import TABLES
+    for name, raw in TABLES.items():
+        cm = mpl.colormaps[name]
+        lut = cm(np.arange(256))[:, :3]
+        want = (255 * np.clip(lut, 0, 1)).astype(np.uint8)
+        assert np.array_equal(np.frombuffer(raw, np.uint8).reshape(256, 3), want), name

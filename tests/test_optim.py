@@ -1,0 +1,126 @@
+"""Optimizer side of the training step: fused Adam over the flat parameter arena against
+torch.optim.Adam, the weight-norm regulariser (run-nerf.py:266-279) against the reference's formula, the arena
+plumbing (parameters / gradients as views, NeRF re-packing after a step)."""
+import ctypes as C
+
+import pytest
+import torch
+
+import fs_nerf_amd  # noqa: F401
+from fs_nerf_amd import _lib as L
+
+
+def test_optimizer_entry_points_validate_without_gpu():
+    lib = L.lib()
+    assert lib.fsn_adam_step(None, None, None, None, 0, 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0, None) == 0  # n = 0
+    assert lib.fsn_adam_step(None, None, None, None, 8, 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0, None) != 0  # null pointers
+    assert lib.fsn_adam_step(None, None, None, None, 8, 0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0, None) != 0  # step 0
+    lens = (C.c_int64 * 2)(10, 20000)
+    assert lib.fsn_weight_norm_workspace_floats(2, lens) == 1 + 3 + 40
+    assert lib.fsn_weight_norm_workspace_floats(99, lens) < 0
+    offs = (C.c_int64 * 2)(0, -5)
+    assert lib.fsn_weight_norm_fwd(None, 2, offs, lens, 0, None, None, None) != 0
+
+
+def _model(dev, seed=0):
+    from fs_nerf_amd.core.models import NeRF
+    torch.manual_seed(seed)
+    m = NeRF(3, 3, 4, 128, (), pos_fn={"n_freqs": 10, "log_space": True}, dir_fn={"n_freqs": 4, "log_space": True})
+    return m.to(dev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wd", [0.0, 1e-2])
+def test_fused_adam_matches_torch_adam(wd):
+    from fs_nerf_amd.core.optim import FusedAdam
+    dev = torch.device("cuda:0")
+    a, b = _model(dev), _model(dev)
+    keys = list(a.state_dict().keys())
+    oa = FusedAdam(a.parameters(), lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+    ob = torch.optim.Adam(b.parameters(), lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd, foreach=False,
+                          fused=False)
+    assert list(a.state_dict().keys()) == keys and oa.arena.attached()
+    assert all(p.data_ptr() == oa.arena.flat.data_ptr() + 4 * o for p, o in zip(oa.arena.params, oa.arena.offsets))
+    gen = torch.Generator(device=dev).manual_seed(1)
+    for step in range(6):
+        oa.zero_grad()
+        ob.zero_grad(set_to_none=True)
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            g = torch.randn(pa.shape, device=dev, generator=gen) * (10.0 ** (step - 3))
+            pa.grad.copy_(g)     # gradients are views into the flat bucket: written in place
+            pb.grad = g.clone()
+        assert all(p.grad.data_ptr() == oa.grads.view(i).data_ptr() for i, p in enumerate(oa.arena.params))
+        oa.step()
+        ob.step()
+        for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
+            assert torch.allclose(pa, pb, rtol=2e-6, atol=1e-9), (step, n, float((pa - pb).abs().max()))
+    # grad_div: an all-reduced SUM over `world` ranks steps like the mean
+    c = _model(dev)
+    oc = FusedAdam(c.parameters(), lr=5e-4)
+    d = _model(dev)
+    od = FusedAdam(d.parameters(), lr=5e-4)
+    oc.zero_grad(); od.zero_grad()
+    for pc, pd in zip(c.parameters(), d.parameters()):
+        g = torch.randn(pc.shape, device=dev, generator=gen)
+        pc.grad.copy_(4.0 * g)
+        pd.grad.copy_(g)
+    oc.step(grad_div=4.0)
+    od.step()
+    assert all(torch.equal(pc, pd) for pc, pd in zip(c.parameters(), d.parameters()))
+
+
+@pytest.mark.gpu
+def test_fused_adam_step_is_seen_by_the_packed_weights():
+    """NeRF.forward runs on the packed blob: it must be re-packed after the optimizer wrote the arena."""
+    from fs_nerf_amd.core.optim import FusedAdam
+    dev = torch.device("cuda:0")
+    m = _model(dev).train()
+    opt = FusedAdam(m.parameters(), lr=1e-2)
+    x = torch.rand(300, 3, device=dev) * 2 - 1
+    d = torch.nn.functional.normalize(torch.randn(300, 3, device=dev), dim=-1)
+    with torch.no_grad():
+        y0 = m.eval()(x, d).clone()
+    m.train()
+    opt.zero_grad()
+    out = m(x, d)
+    out.square().mean().backward()
+    assert float(opt.grads.flat.abs().max()) > 0.0, "autograd accumulated into the flat bucket"
+    opt.step()
+    with torch.no_grad():
+        y1 = m.eval()(x, d)
+    assert float((y1 - y0).abs().max()) > 1e-4, "the forward must see the stepped parameters"
+    ref = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    assert torch.equal(ref, opt.arena.flat)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reg", ["l1", "l2"])
+@pytest.mark.parametrize("arena", [True, False])
+def test_weight_norm_regulariser_matches_the_reference_formula(reg, arena):
+    from fs_nerf_amd.core.loss import WeightNormRegularizer
+    from fs_nerf_amd.core.optim import FlatParams
+    dev = torch.device("cuda:0")
+    m = _model(dev, seed=3)
+    if arena:
+        FlatParams(m.parameters())
+    wn = WeightNormRegularizer(m.named_parameters(), reg=reg, reg_ratio=0.5, Td=100)
+    names = [n for n, p in m.named_parameters() if "weight" in n and p.shape[0] > 3]
+    assert len(wn.params) == len(names) == 6 and "rgb.weight" not in names and "sigma.weight" not in names
+    assert wn.active(49) and not wn.active(50)
+    val = wn()
+    (0.37 * val).backward()
+    # the reference's loop (run-nerf.py:272-277), on float64 copies
+    ps = {n: p.detach().double().clone().requires_grad_(True) for n, p in m.named_parameters()}
+    want = torch.zeros((), dtype=torch.float64, device=dev)
+    for n, p in ps.items():
+        if "weight" in n and p.shape[0] > 3:
+            want = want + (torch.abs(p).sum() if reg == "l1" else torch.square(p).sum().sqrt())
+    (0.37 * want).backward()
+    assert abs(float(val) - float(want)) <= 2e-6 * float(want)
+    for n, p in m.named_parameters():
+        if n in names:
+            assert torch.allclose(p.grad.double(), ps[n].grad, rtol=1e-5, atol=1e-7), n
+        else:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+    # bit-reproducible (fixed summation order, no atomics)
+    assert float(wn()) == float(val)

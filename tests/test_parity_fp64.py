@@ -372,3 +372,28 @@ def test_rendering_accepts_int32_ray_indices_with_backward(dev):
         assert torch.equal(a, b)
     with pytest.raises((RuntimeError, TypeError)):
         Rm.rendering(t0.to(dev), t1.to(dev), ri64.to(dev).float(), R, lambda a, b, i: (rgb.to(dev), sig.to(dev)), None)
+
+
+def test_two_phase_and_camera_modes_are_bitwise_the_plain_launch(dev):
+    """The optional launch shapes change scheduling only: rays generated in the launch from the pose == get_rays
+    tensors; "all coarse passes, then all fine passes" (edges handed over through HBM) == group by group."""
+    from fs_nerf_amd import ops
+    L, D = 4, 128
+    mc, mf = hip_model(make_sd(L, D, 42), L, D, dev, "fp16x3"), hip_model(make_sd(L, D, 43), L, D, dev, "fp16x3")
+    pose = O.pose_from_spherical(4.0311289, 50.0, 123.0)
+    H, W, focal = 150, 201, 260.0
+    kw = dict(near=2.0, far=6.0, n_samples=64, n_importance=128, bkgd=(1.0, 1.0, 1.0), want_extras=False)
+    o, d = ops.get_rays(pose, H, W, focal, dev)
+    base = ops.render_fused(mc.packed(), mf.packed(), o, d, two_phase=False, **kw)
+    cam = ops.render_fused(mc.packed(), mf.packed(), None, None, camera=(pose, H, W, focal, 0, H, dev), two_phase=False, **kw)
+    two = ops.render_fused(mc.packed(), mf.packed(), None, None, camera=(pose, H, W, focal, 0, H, dev), two_phase=True, **kw)
+    rows = ops.render_fused(mc.packed(), mf.packed(), None, None, camera=(pose, H, W, focal, 40, 30, dev), two_phase=True, **kw)
+    for k in range(3):
+        assert torch.equal(base[k], cam[k]) and torch.equal(base[k], two[k])
+        assert torch.equal(rows[k], base[k][40 * W:70 * W]), "a row block of the frame (a rank's shard)"
+    ex = ops.render_fused(mc.packed(), mf.packed(), o, d, two_phase=True, near=2.0, far=6.0, n_samples=64,
+                          n_importance=128, bkgd=(1.0, 1.0, 1.0), want_extras=True)
+    ex1 = ops.render_fused(mc.packed(), mf.packed(), o, d, two_phase=False, near=2.0, far=6.0, n_samples=64,
+                           n_importance=128, bkgd=(1.0, 1.0, 1.0), want_extras=True)
+    for k in ("weights", "edges", "weights_coarse", "rgbs"):
+        assert torch.equal(ex[3][k], ex1[3][k]), k

@@ -382,3 +382,45 @@ def test_gradient_allreduce_fixed_bucket_with_missing_grads_gloo():
         assert p.exitcode == 0
     assert res[0][1] == res[1][1], "ranks disagree after the all-reduce"
     assert all(r[2] for r in res) and all(r[3] == 5 * 7 + 7 + 7 * 3 + 3 for r in res)
+
+
+@pytest.mark.gpu
+def test_training_range_guard_zeroes_gradients_on_device_then_continues_in_bf16x3():
+    """Hidden activations beyond the fp16 range during training: the step's gradients are written as zeros by the
+    backward kernels themselves (no host sync, no inf / NaN reaches the optimizer); at its next amortised look at the
+    status word the host warns and the model continues in bf16x3, where the gradients are right again."""
+    from fs_nerf_amd import ops
+    from fs_nerf_amd.core.models import NeRF
+    from test_parity_fp64 import cfg_of, scaled_sd
+    dev = torch.device("cuda:0")
+    L, D, N = 8, 256, 600
+    sd = scaled_sd(L, D, 43, 4e5)
+    m = NeRF(3, 3, L, D, (4,), pos_fn={"n_freqs": 10, "log_space": True}, dir_fn={"n_freqs": 4, "log_space": True})
+    m.load_state_dict(sd)
+    m = m.to(dev).train()
+    m.range_check_every = 2
+    gen = torch.Generator().manual_seed(2)
+    x = (torch.rand(N, 3, generator=gen) * 2 - 1).to(dev)
+    d = torch.nn.functional.normalize(torch.randn(N, 3, generator=gen), dim=-1).to(dev)
+    c = torch.randn(N, 4, generator=gen).to(dev)
+    assert ops.range_ok(dev)
+    (m(x, d) * c).sum().backward()  # step 1: flagged on the device, not yet seen by the host
+    assert m.precision == "fp16x3"
+    for name, p in m.named_parameters():
+        assert float(p.grad.abs().max()) == 0.0, f"{name}: a flagged step must leave zero gradients"
+    m.zero_grad(set_to_none=True)
+    with pytest.warns(RuntimeWarning, match="fp16 range"):
+        (m(x, d) * c).sum().backward()  # step 2: the host looks at the status word
+    assert m.precision == "bf16x3"
+    m.zero_grad(set_to_none=True)
+    out = m(x, d)
+    (out * c).sum().backward()  # step 3: bf16x3
+    sdr = {k: v.detach().double().clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.nerf_forward(sdr, x.cpu().double(), d.cpu().double(), **cfg_of(L))
+    (ref * c.cpu().double()).sum().backward()
+    assert bool(torch.isfinite(out).all()) and _rel(out, ref) < 1e-3
+    for name, p in m.named_parameters():
+        assert bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().max()) > 0.0, name
+        if name in ("rgb.weight", "rgb.bias", "branch.bias", "sigma.bias"):
+            assert _rel(p.grad, sdr[name].grad) < 5e-2, name
+    assert ops.range_ok(dev)
