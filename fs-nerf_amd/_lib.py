@@ -127,7 +127,10 @@ def lib() -> C.CDLL:
             raise RuntimeError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(there is no CPU fallback for the HIP path)")
         l = C.CDLL(LIB_PATH)
+        partial = os.environ.get("FSN_LIB_PARTIAL") == "1"  # the sanitizer build of the host side exports a subset
         for name, (res, args) in SIGNATURES.items():
+            if partial and not hasattr(l, name):
+                continue
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
         _lib = l

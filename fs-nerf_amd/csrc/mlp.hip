@@ -6,83 +6,12 @@
 #define FSN_X3_PF1
 #include "mlp_dev.hpp"
 #include "mlp_layout.hpp"
+#include "mlp_pack.hpp"
 
 #include <cstring>
 #include <vector>
 
 namespace fsn {
-
-// ------------------------------------------------------------------ packing
-struct PackArgs {
-  NetGeom G;
-  const float* W[kMaxLayers + 4];  // layers.0.., sigma, connection, branch, rgb (reference order)
-  const float* b[kMaxLayers + 4];
-  int32_t n_layers, d_hidden, prec;
-  uint32_t skip_mask;
-  int32_t n_freqs_pos, n_freqs_dir;
-  float freqs_pos[16], freqs_dir[16];
-};
-
-// weight index (state_dict order) of GEMM g (kernel order: hidden 0..L-1, connection, branch)
-FSN_HD int gemm_to_sd(int g, int L) { return g < L ? g : g + 1; }  // skips "sigma" at index L
-
-// One 16-byte piece = 8 bf16 of (unit, part hi/lo, lane).  Shared by host and device packers.
-FSN_HD void pack_piece(const PackArgs& a, int64_t piece, uint16_t out8[8]) {
-  const int ub = unit_bytes(a.prec);
-  const int ppu = ub / 16;  // pieces per unit
-  const int unit = (int)(piece / ppu);
-  const int rem = (int)(piece - (int64_t)unit * ppu);
-  const int part = rem >> 6, lane = rem & 63;
-  for (int j = 0; j < 8; ++j) out8[j] = 0;
-  if (unit >= a.G.units_total) return;  // tail padding of the last phase
-  int g = 0;
-  while (g + 1 < a.G.n_gemm && a.G.g[g + 1].unit0 <= unit) ++g;
-  const LayerGeom& Lg = a.G.g[g];
-  const int ks_tot = Lg.ks_act + Lg.ks_enc;
-  const int lu = unit - Lg.unit0;          // ((pair * ks_tot) + ks) * 2 + half
-  const int sub = lu & 1;
-  const int t = (lu >> 1) / ks_tot, ks = (lu >> 1) - t * ks_tot;
-  const int r = lane & 15, grp = lane >> 4;
-  const float* W = a.W[gemm_to_sd(g, a.n_layers)];
-  const int row = 32 * t + 16 * sub + r;
-  for (int j = 0; j < 8; ++j) {
-    const int col = unit_src_col(Lg, ks, grp, j);
-    if (col < 0) continue;
-    const float w = W[(int64_t)row * Lg.ld + col];
-    const bool f16 = prec_is_f16(a.prec);
-    const uint16_t hi = half_rne(w, f16);
-    out8[j] = part == 0 ? hi : half_rne(w - half_to_f32(hi, f16), f16);
-  }
-}
-
-// aux float `i` of the blob
-FSN_HD float aux_value(const PackArgs& a, int i) {
-  const int D = a.d_hidden, L = a.n_layers;
-  const int blk = i / D, off = i - blk * D;
-  if (blk < L) return a.b[blk][off];                          // hidden biases
-  if (blk == L) return a.b[L + 1][off];                       // connection bias
-  if (blk == L + 1) return off < D / 2 ? a.b[L + 2][off] : 0.f;  // branch bias
-  if (blk == L + 2) return a.W[L][off];                       // sigma.weight [1,D]
-  if (blk == L + 3 || blk == L + 4) {                         // rgb.weight [3,D/2]
-    const int k = i - (L + 3) * D;
-    return k < 3 * (D / 2) ? a.W[L + 3][k] : 0.f;
-  }
-  const int m = i - (L + 5) * D;
-  if (m == 0) return a.b[L][0];                 // sigma.bias
-  if (m >= 1 && m <= 3) return a.b[L + 3][m - 1];  // rgb.bias
-  if (m >= 4 && m < 20) return a.freqs_pos[m - 4];
-  if (m >= 20 && m < 36) return a.freqs_dir[m - 20];
-  return 0.f;
-}
-
-FSN_HD void header_words(const PackArgs& a, uint32_t hw[64]) {
-  for (int i = 0; i < 64; ++i) hw[i] = 0;
-  hw[0] = kBlobMagic; hw[1] = 1; hw[2] = (uint32_t)a.prec; hw[3] = (uint32_t)a.n_layers;
-  hw[4] = (uint32_t)a.d_hidden; hw[5] = a.skip_mask; hw[6] = (uint32_t)a.n_freqs_pos;
-  hw[7] = (uint32_t)a.n_freqs_dir; hw[8] = (uint32_t)a.G.units_total; hw[9] = (uint32_t)a.G.nph_full;
-  hw[10] = (uint32_t)a.G.nph_density; hw[11] = (uint32_t)a.G.aux_off; hw[12] = (uint32_t)a.G.aux_floats;
-  hw[13] = (uint32_t)a.G.stream_off; hw[14] = (uint32_t)(a.G.total_bytes & 0xffffffffu);
-}
 
 __global__ void k_pack_stream(PackArgs a, char* __restrict__ blob, int64_t n_pieces) {
   const int64_t piece = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -112,19 +41,9 @@ __global__ void k_pack_aux(PackArgs a, char* __restrict__ blob) {
 
 static int fill_pack_args(const fsn_mlp_desc* d, int prec, const float* const* W, const float* const* b,
                           PackArgs& a) {
-  FSN_REQUIRE(d && W && b, FSN_E_INVALID, "mlp_pack: null pointer");
   const char* why;
-  const int rc = build_geom(*d, prec, a.G, &why);
+  const int rc = fill_pack_args_raw(d, prec, W, b, a, &why);
   FSN_REQUIRE(rc == FSN_OK, rc, "mlp_pack: %s", why);
-  for (int i = 0; i < d->n_layers + 4; ++i) {
-    FSN_REQUIRE(W[i] && b[i], FSN_E_INVALID, "mlp_pack: null weight/bias %d", i);
-    a.W[i] = W[i];
-    a.b[i] = b[i];
-  }
-  a.n_layers = d->n_layers; a.d_hidden = d->d_hidden; a.prec = prec; a.skip_mask = d->skip_mask;
-  a.n_freqs_pos = d->n_freqs_pos; a.n_freqs_dir = d->n_freqs_dir;
-  std::memcpy(a.freqs_pos, d->freqs_pos, sizeof(a.freqs_pos));
-  std::memcpy(a.freqs_dir, d->freqs_dir, sizeof(a.freqs_dir));
   return FSN_OK;
 }
 
@@ -240,19 +159,9 @@ extern "C" int fsn_mlp_pack(const fsn_mlp_desc* desc, int prec, const float* con
 extern "C" int fsn_mlp_pack_host(const fsn_mlp_desc* desc, int prec, const float* const* weights,
                                  const float* const* biases, void* blob_host) {
   FSN_REQUIRE(blob_host, FSN_E_INVALID, "fsn_mlp_pack_host: null blob");
-  PackArgs a;
-  const int rc = fill_pack_args(desc, prec, weights, biases, a);
-  if (rc != FSN_OK) return rc;
-  char* blob = static_cast<char*>(blob_host);
-  std::memset(blob, 0, (size_t)a.G.total_bytes);
-  uint32_t hw[64];
-  header_words(a, hw);
-  std::memcpy(blob, hw, sizeof(hw));
-  float* aux = reinterpret_cast<float*>(blob + a.G.aux_off);
-  for (int i = 0; i < a.G.aux_floats; ++i) aux[i] = aux_value(a, i);
-  const int64_t n_pieces = (int64_t)a.G.nph_full * kPhaseBytes / 16;
-  uint16_t* sp = reinterpret_cast<uint16_t*>(blob + a.G.stream_off);
-  for (int64_t p = 0; p < n_pieces; ++p) pack_piece(a, p, sp + p * 8);
+  const char* why;
+  const int rc = pack_blob_host(desc, prec, weights, biases, blob_host, &why);
+  FSN_REQUIRE(rc == FSN_OK, rc, "fsn_mlp_pack_host: %s", why);
   return FSN_OK;
 }
 
