@@ -377,7 +377,7 @@ def main():
         rgb, op, depth, _ = ops.render_fused(pc, pf, None, None, near=NEAR, far=FAR, n_samples=S, n_importance=NI,
                                              bkgd=(1.0, 1.0, 1.0), want_extras=False,
                                              camera=(pose, H, W, FOCAL, 0, H, dev),
-                                             two_phase=os.environ.get("FSN_TWO_PHASE", "0") == "1")
+                                             two_phase=os.environ.get("FSN_TWO_PHASE", "1") == "1")
         e1.record()
         if timed:
             ev.append((e0, e1))

@@ -17,6 +17,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fs_nerf_amd  # noqa: E402,F401
 from fs_nerf_amd.core import models as M  # noqa: E402
+from fs_nerf_amd.core.loss import WeightNormRegularizer  # noqa: E402
+from fs_nerf_amd.core.optim import FusedAdam  # noqa: E402
 from fs_nerf_amd.core.scheduler import ExponentialDecay  # noqa: E402
 from fs_nerf_amd.render import rendering as R  # noqa: E402
 from fs_nerf_amd.render.occgrid import OccGridEstimator  # noqa: E402
@@ -68,7 +70,9 @@ def main():
     else:
         estimator = R.StratifiedEstimator(near, far, 64, 128)
     estimator.train()
-    optimizer = torch.optim.Adam(model.parameters(), lr=5e-4)
+    optimizer = FusedAdam(model.parameters(), lr=5e-4)  # torch.optim.Adam's arithmetic, one launch over flat arenas
+    wnorm = WeightNormRegularizer(model.named_parameters(), reg="l2", reg_ratio=0.5, Td=a.iters)  # run-nerf.py:266-279
+    alpha = 1e-5
     scheduler = ExponentialDecay(optimizer, a.iters, 5e-4, r=0.1)
     gen = torch.Generator(device=dev).manual_seed(0)
 
@@ -81,6 +85,8 @@ def main():
         (rgb, _, depth, _), _, _ = R.render_rays(ro[idx], rd[idx], estimator, model, train=True, white_bkgd=True,
                                                  render_step_size=step, device=dev)
         loss = torch.nn.functional.mse_loss(rgb, gt[idx])
+        if wnorm.active(k):
+            loss = loss + alpha * wnorm()
         loss.backward()
         optimizer.step()
         scheduler.step()

@@ -215,6 +215,10 @@ struct WStream {
   // part in the same number of events when the pass ends.  No staging, no waits: events only.
   static __device__ __forceinline__ bool lagging() { return kLag && (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256); }
   __device__ __forceinline__ void pass_begin() const {
+#ifdef FSN_ABL_LAGSLEEP  // timing experiment (with the barrier-free ablation of the generator): waves 4..7 start every
+    // pass FSN_ABL_LAGSLEEP x 64 cycles late, so that the two waves of a SIMD run out of step
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_sleep(FSN_ABL_LAGSLEEP);
+#endif
     if (kLag && lagging()) asm volatile("s_barrier" ::: "memory");
   }
   __device__ __forceinline__ void pass_end() const {
@@ -417,9 +421,13 @@ struct AFrag {  // A operand (weights) of one unit
 #ifndef FSN_KLOOP_D
 #define FSN_KLOOP_D 2
 #endif
-constexpr int kKD = FSN_KLOOP_D;  // A-operand units in flight ahead of the MFMAs on the hand-scheduled path
+#ifndef FSN_KLOOP_NSETS
+#define FSN_KLOOP_NSETS (FSN_KLOOP_D + 1)
+#endif
+constexpr int kKD = FSN_KLOOP_D;  // A-operand units landed ahead of a pair on entry to a hand-scheduled block
+constexpr int kNS = FSN_KLOOP_NSETS;  // A register sets in rotation (unit u lives in set u mod kNS)
 struct ARing {
-  AFrag cur[4];  // hand-scheduled path: kKD + 1 sets in rotation; compiler-scheduled prefetch modes: cur[0..1]
+  AFrag cur[kNS > 3 ? kNS : 3];  // hand-scheduled path: kNS sets in rotation; compiler-scheduled prefetch modes: cur[0..1]
 };
 template <int PREC>
 __device__ __forceinline__ void load_afrag(const char* p, AFrag& f) {
@@ -595,7 +603,7 @@ struct AccSets {
 };
 
 #define FSN_KLOOP_PIN "+{v[240:243]}"(acc.e0), "+{v[244:247]}"(acc.e1), "+{v[248:251]}"(acc.o0), "+{v[252:255]}"(acc.o1)
-#if FSN_KLOOP_D == 3
+#if FSN_KLOOP_NSETS == 4
 #define FSN_KLOOP_SETS_X3                                                                                        \
   [s0h] "+v"(s0.hi), [s0l] "+v"(s0.lo), [s1h] "+v"(s1.hi), [s1l] "+v"(s1.lo), [s2h] "+v"(s2.hi), [s2l] "+v"(s2.lo), \
       [s3h] "+v"(s3.hi), [s3l] "+v"(s3.lo), [keep] "=&s"(keep)
@@ -771,7 +779,7 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
       constexpr int EKS = decltype(EKS_)::value;  // 0: epilogue after each pair; 1 / 2: deferred into the next pair
       static_for<NP_OUT>([&](auto TP) __attribute__((always_inline)) {
         constexpr int tp = decltype(TP)::value;
-        constexpr int NS = kKD + 1;  // A register sets
+        constexpr int NS = kNS;  // A register sets
         constexpr int R0 = (tp * NU) % NS, OFF = (tp * NU) % UPP, PAR = tp & 1;
         constexpr int EK = tp == 0 ? 0 : EKS;
         hk.pre(tp);
@@ -784,7 +792,7 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
         const uint32_t abn = bias_lds + 128u * (tp + 1 < NP_OUT ? tp + 1 : tp);  // (last pair: a harmless reload)
         kloop_block<F16, PREC == 6, KS_ACT, KS_ENC, OFF, EK, PAR>(
             st, act, enc, acc, abn, ring.cur[R0], ring.cur[(R0 + 1) % NS], ring.cur[(R0 + 2) % NS],
-            ring.cur[(R0 + 3) % NS == R0 ? 3 : (R0 + 3) % NS], out[tp > 0 && tp - 1 < NOUT ? tp - 1 : 0], heads.fmax);
+            ring.cur[NS > 3 ? (R0 + 3) % NS : 0], out[tp > 0 && tp - 1 < NOUT ? tp - 1 : 0], heads.fmax);
 #ifdef FSN_STAMP
         const uint64_t ts1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -814,13 +822,13 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
       run(std::integral_constant<int, 0>{});
     }
     // bring the sets holding the next GEMM's first kKD units back to cur[0..kKD-1]
-    constexpr int RE = TOTAL % (kKD + 1);
+    constexpr int RE = TOTAL % kNS;
     if constexpr (RE != 0) {
-      AFrag t[kKD + 1];
+      AFrag t[kNS];
 #pragma unroll
-      for (int i = 0; i <= kKD; ++i) t[i] = ring.cur[(RE + i) % (kKD + 1)];
+      for (int i = 0; i < kNS; ++i) t[i] = ring.cur[(RE + i) % kNS];
 #pragma unroll
-      for (int i = 0; i <= kKD; ++i) ring.cur[i] = t[i];
+      for (int i = 0; i < kNS; ++i) ring.cur[i] = t[i];
     }
     return;
   }
@@ -917,7 +925,7 @@ __device__ __forceinline__ void prime_ring(const WStream& st, ARing& ring) {
 #pragma unroll
     for (int i = 0; i < kKD; ++i) load_afrag<PREC>(st.n_base + i * UB, ring.cur[i]);
 #pragma unroll
-    for (int i = kKD; i < 4; ++i) ring.cur[i] = ring.cur[0];
+    for (int i = kKD; i < (kNS > 3 ? kNS : 3); ++i) ring.cur[i] = ring.cur[0];
     return;
   }
 #ifdef FSN_X3_PF1

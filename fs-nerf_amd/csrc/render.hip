@@ -86,7 +86,7 @@ struct RaySrc {
 #ifdef FSN_STAMP
 __device__ unsigned long long g_stamp[256 * 8 * 8];
 #endif
-template <int NT, int PREC>
+template <int NT, int PREC, bool TWO_PHASE>
 __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
 #ifdef FSN_STAMP
   const uint64_t t_begin = __builtin_amdgcn_s_memtime();
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
     lds_barrier();
   };
   const int64_t ngroups = (GRP_R + GRP_G - 1) / GRP_G;
-  if (!S_.two_phase) {
+  if constexpr (!TWO_PHASE) {
     // one group at a time: coarse pass, resampling, fine pass, integration (the weight stream alternates between
     // the two networks; small launches, or no hand-over buffer)
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
@@ -276,7 +276,10 @@ template <int NT, int PREC>
 static int launch_render(const RenderKArgs& k, int cus, hipStream_t s) {
   const int64_t ngroups = (k.a.R + k.G - 1) / k.G;
   const unsigned grid = (unsigned)(ngroups < cus ? ngroups : cus);
-  k_render_fused<NT, PREC><<<grid, kThreads, 0, s>>>(k);
+  // (two instantiations: the two-phase variant's second copy of both MLP passes costs registers and code the usual
+  // launch should not pay for)
+  if (k.two_phase) k_render_fused<NT, PREC, true><<<grid, kThreads, 0, s>>>(k);
+  else k_render_fused<NT, PREC, false><<<grid, kThreads, 0, s>>>(k);
   FSN_LAUNCH_CHECK("k_render_fused");
   return FSN_OK;
 }

@@ -48,11 +48,13 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ABL = os.environ.get("FSN_KLOOP_ABL", "")
 WAIT2 = os.environ.get("FSN_KLOOP_WAIT2", "1") == "1"
+ILV = os.environ.get("FSN_KLOOP_ILV", "0") == "1"
 UPP = 8        # units per 16-KiB phase (a unit = 1 KiB high + 1 KiB low parts)
 UB = 2048      # bytes per unit in the x3 stream layout
 D = int(os.environ.get("FSN_KLOOP_D", "2"))   # units of A operands in flight ahead of the MFMAs (D + 1 register sets)
 LEAD = D       # a phase is opened LEAD units before the previous one ends
 LOADS = 4     # LDS-DMA loads (1 KiB each) of a loader wave per phase: four loader waves x 4 KiB
+NSETS = 4 if (os.environ.get("FSN_KLOOP_ILV", "0") == "1") else int(os.environ.get("FSN_KLOOP_D", "2")) + 1  # A register sets
 SETS = {0: (240, 248), 1: (248, 240)}  # parity -> (first register of the current set, of the other set)
 
 
@@ -110,7 +112,7 @@ def block(mode, nu, off, kind, par):
     def read(u):
         gu = off + u
         ph, o = gu // UPP, (gu % UPP) * UB
-        s = u % (D + 1)
+        s = u % NSETS
         emit(f"ds_read_b128 %[s{s}h], %[a{ph}] offset:{o}", True)
         if mode == "X3":
             emit(f"ds_read_b128 %[s{s}l], %[a{ph}] offset:{o + 1024}", True)
@@ -156,17 +158,35 @@ def block(mode, nu, off, kind, par):
             fill[:] = bias           # (the two bias reads follow behind the next MFMAs)
             per_unit = 3
             share = [1, 1, 1] if mode == "X3" else [2, 1]
-        read(u + D)
+        if ILV and D == 2:
+            if u % 2 == 0:   # both units of the next k-step, into the two sets the previous k-step has released
+                read(u + 2)
+                read(u + 3)
+        else:
+            read(u + D)
         # Every read of the units about to be used must have landed; LDS returns in order, so allow the reads issued
         # after their last one.  WAIT2 (default): one wait per k-step, in front of its first unit, covering both
         # of its units (one instruction less per k-step; the second unit's reads were issued a k-step ago).
-        if WAIT2 and D == 2 and mode == "X3":  # (x2: measured 1.5 % slower with the merged wait)
+        if ILV and D == 2:
+            if u % 2 == 0:
+                ins.append(f"s_waitcnt lgkmcnt({state['n_lds'] - max(unit_last_read[u], unit_last_read.get(u + 1, 0))})")
+        elif WAIT2 and D == 2 and mode == "X3":  # (x2: measured 1.5 % slower with the merged wait)
             if u % 2 == 0:
                 last = max(unit_last_read[u], unit_last_read.get(u + 1, 0))
                 ins.append(f"s_waitcnt lgkmcnt({state['n_lds'] - last})")
         else:
             ins.append(f"s_waitcnt lgkmcnt({state['n_lds'] - unit_last_read[u]})")
-        k, t, s = u // 2, u % 2, u % (D + 1)
+        k, t, s = u // 2, u % 2, u % NSETS
+        if ILV and D == 2:
+            # the two units of a k-step interleaved MFMA by MFMA: consecutive MFMAs never share an accumulator
+            if t == 0:
+                continue
+            s0 = (u - 1) % NSETS
+            mfma(0, f"{s0}h", f"{k}h", share[0]); mfma(1, f"{s}h", f"{k}h", 0)
+            if mode == "X3":
+                mfma(0, f"{s0}l", f"{k}h", share[1]); mfma(1, f"{s}l", f"{k}h", 0)
+            mfma(0, f"{s0}h", f"{k}l", share[-1]); mfma(1, f"{s}h", f"{k}l", 0)
+            continue
         mfma(t, f"{s}h", f"{k}h", share[0])
         if mode == "X3":
             mfma(t, f"{s}l", f"{k}h", share[1])
@@ -207,6 +227,7 @@ def main():
         out.append(f"#define FSN_KLOOP_{nu}_{off}_EVENTS {ev}")
         out.append(f"#define FSN_KLOOP_{nu}_{off}_PHASES {n_phases(nu, off)}")
     out.append(f"#define FSN_KLOOP_D {D}")
+    out.append(f"#define FSN_KLOOP_NSETS {NSETS}")
     out.append("")
     for mode in ("X3", "X2"):
         for nu, off in SHAPES:
