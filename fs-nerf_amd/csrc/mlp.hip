@@ -76,18 +76,23 @@ struct TileSrc {
   __device__ __forceinline__ void dir(float& x, float& y, float& z) const { x = p[3]; y = p[4]; z = p[5]; }
 };
 
-// Persistent workgroups; tile = 128 consecutive samples; wave w / lane (c = lane&15, g = lane>>4)
-// owns sample 128*tile + 16*w + c.  LDS: [weight ring 64 KiB][aux + masks][tile inputs 128 x 6 floats].
+// Persistent workgroups; tile = 128 NG consecutive samples; wave w / lane (c = lane&15, g = lane>>4) owns samples
+// tile0 + 16*(NG*w + q) + c, q < NG (NG = 2 sample groups per wave in the single-pass modes of 256-wide networks,
+// mlp_dev.hpp gemm_layer2).  LDS: [weight ring 64 KiB][aux + masks][tile inputs 128 NG x 6 floats].
+template <int NT, int PREC>
+constexpr int groups_per_wave() { return ((PREC & 1) == 1 && NT == 8) ? 2 : 1; }
+
 template <int NT, int PREC, bool FULL>
 __global__ __launch_bounds__(kThreads) void k_mlp_fwd(MlpFwdArgs a) {
-  __shared__ __attribute__((aligned(1024))) char smem[kRingBytes + (kAuxCapFloats + 96) * 4 + 128 * 6 * 4];
+  constexpr int NG = groups_per_wave<NT, PREC>(), TILE = 128 * NG;
+  __shared__ __attribute__((aligned(1024))) char smem[kRingBytes + (kAuxCapFloats + 96) * 4 + TILE * 6 * 4];
   float* aux_lds = reinterpret_cast<float*>(smem + kRingBytes);
   float* in_lds = aux_lds + kAuxCapFloats + 96;
   NetDev net;
   load_net(a.net, a.pos_mask, a.dir_mask, aux_lds, net);
   __syncthreads();
   constexpr bool full = FULL;
-  const int64_t ntiles = (a.n + 127) / 128;
+  const int64_t ntiles = (a.n + TILE - 1) / TILE;
   WStream st;
   const char* sbase = a.net.blob + a.net.stream_off;
   st.init(smem, nullptr, 0, 0, sbase, (uint32_t)(full ? a.net.nph_full : a.net.nph_density), 1);
@@ -95,23 +100,43 @@ __global__ __launch_bounds__(kThreads) void k_mlp_fwd(MlpFwdArgs a) {
   ARing ring;
   prime_ring<PREC, NT>(st, ring);
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t s = tile * 128 + wave * 16 + (lane & 15);
-    const int64_t sc = s < a.n ? s : a.n - 1;
-    if (lane < 16) {  // each wave stages (and later reads) only its own 16 samples: no workgroup barrier
-      float* q = in_lds + (wave * 16 + lane) * 6;
+    // each wave stages (and later reads) only its own 16 NG samples: no workgroup barrier
+    if (lane < 16 * NG) {
+      const int64_t s = tile * TILE + wave * (16 * NG) + lane;
+      const int64_t sc = s < a.n ? s : a.n - 1;
+      float* q = in_lds + (wave * (16 * NG) + lane) * 6;
       q[0] = a.x[3 * sc]; q[1] = a.x[3 * sc + 1]; q[2] = a.x[3 * sc + 2];
       if (full) { q[3] = a.dirs[3 * sc]; q[4] = a.dirs[3 * sc + 1]; q[5] = a.dirs[3 * sc + 2]; }
     }
     __builtin_amdgcn_wave_barrier();
-    const TileSrc src{in_lds + (wave * 16 + (lane & 15)) * 6};
-    float sigma, rgb[3] = {0.f, 0.f, 0.f};
-    mlp_tile<NT, PREC, FULL>(st, net, src, ring, sigma, rgb);
-    if (lane < 16 && s < a.n) {
-      if (full) {
-        f32x4 o = {rgb[0], rgb[1], rgb[2], sigma};
-        *reinterpret_cast<f32x4*>(a.out + 4 * s) = o;
-      } else {
-        a.out[s] = sigma;
+    const int64_t s = tile * TILE + wave * (16 * NG) + (lane & 15);
+    if constexpr (NG == 1) {
+      const TileSrc src{in_lds + (wave * 16 + (lane & 15)) * 6};
+      float sigma, rgb[3] = {0.f, 0.f, 0.f};
+      mlp_tile<NT, PREC, FULL>(st, net, src, ring, sigma, rgb);
+      if (lane < 16 && s < a.n) {
+        if (full) {
+          f32x4 o = {rgb[0], rgb[1], rgb[2], sigma};
+          *reinterpret_cast<f32x4*>(a.out + 4 * s) = o;
+        } else {
+          a.out[s] = sigma;
+        }
+      }
+    } else {
+      const TileSrc src0{in_lds + (wave * 32 + (lane & 15)) * 6}, src1{in_lds + (wave * 32 + 16 + (lane & 15)) * 6};
+      float sigma[2], rgb[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+      mlp_tile2<NT, PREC, FULL>(st, net, src0, src1, ring, sigma, rgb);
+      if (lane < 32) {  // lanes 0-15 write group 0, lanes 16-31 group 1 (every lane holds both results)
+        const int q = lane >> 4;
+        const int64_t sq = s + 16 * q;
+        if (sq < a.n) {
+          if (full) {
+            f32x4 o = {rgb[q][0], rgb[q][1], rgb[q][2], sigma[q]};
+            *reinterpret_cast<f32x4*>(a.out + 4 * sq) = o;
+          } else {
+            a.out[sq] = sigma[q];
+          }
+        }
       }
     }
   }
@@ -120,7 +145,8 @@ __global__ __launch_bounds__(kThreads) void k_mlp_fwd(MlpFwdArgs a) {
 
 template <int NT, int PREC>
 static int launch_mlp_fwd(const MlpFwdArgs& a, int cus, hipStream_t s) {
-  const int64_t ntiles = (a.n + 127) / 128;
+  constexpr int TILE = 128 * groups_per_wave<NT, PREC>();
+  const int64_t ntiles = (a.n + TILE - 1) / TILE;
   const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
   if (a.dirs) k_mlp_fwd<NT, PREC, true><<<grid, kThreads, 0, s>>>(a);
   else k_mlp_fwd<NT, PREC, false><<<grid, kThreads, 0, s>>>(a);

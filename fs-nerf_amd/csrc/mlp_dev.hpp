@@ -917,6 +917,134 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
   gemm_layer<PREC, NP_OUT, KS_ACT, KS_ENC, EPI>(st, net, aux_bias, act, enc, out, heads, ring, g, hk);
 }
 
+// ---------------------------------------------------------------- two sample groups per wave (single-pass modes)
+// 32 samples per wave as two 16-sample groups that share every A operand: one ds_read_b128 feeds two MFMAs, and a
+// 16-KiB weight phase (one barrier, one round of LDS-DMA) covers 256 samples of the workgroup instead of 128.  The
+// single-pass modes carry no low parts, so both groups' activations (2 x 64 registers in, 2 x 64 out) still fit two
+// waves per SIMD.  Same blob, same unit order, same epilogue arithmetic per group as gemm_layer.
+template <int PREC, int NP_OUT, int KS_ACT, int KS_ENC, int EPI, int NACT, int NENC, int NOUT>
+__device__ __forceinline__ void gemm_layer2(WStream& st, const NetDev& net, int aux_bias, const Frag (&act0)[NACT],
+                                            const Frag (&act1)[NACT], const Frag (&enc0)[NENC], const Frag (&enc1)[NENC],
+                                            Frag (&out0)[NOUT], Frag (&out1)[NOUT], Heads& heads0, Heads& heads1,
+                                            ARing& ring, int g) {
+  constexpr bool F16 = PREC >= 2;
+  static_assert((PREC & 1) == 1, "two groups per wave: single-pass modes only");
+  constexpr int UPP = 16, UB = 1024;
+  constexpr int KS = KS_ACT + KS_ENC;
+  constexpr int TOTAL = 2 * NP_OUT * KS;
+  static_assert(KS_ACT <= NACT && KS_ENC <= NENC, "operand arrays too small");
+  const float* bias = net.aux + aux_bias;
+  NoHook hk;
+#pragma unroll
+  for (int tp = 0; tp < NP_OUT; ++tp) {
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + 32 * tp + 4 * g);
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + 32 * tp + 16 + 4 * g);
+    f32x4 a00 = b0, a01 = b1, a10 = b0, a11 = b1;  // [group][tile]
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const Frag& x0 = ks < KS_ACT ? act0[ks < KS_ACT ? ks : 0] : enc0[ks >= KS_ACT ? ks - KS_ACT : 0];
+      const Frag& x1 = ks < KS_ACT ? act1[ks < KS_ACT ? ks : 0] : enc1[ks >= KS_ACT ? ks - KS_ACT : 0];
+      const int u = (tp * KS + ks) * 2;  // compile-time after unrolling
+      if (((u + kLead) % UPP == 0 && u + kLead <= TOTAL) || (u + kLead == TOTAL && TOTAL % UPP != 0)) st.open_next();
+      if (u % UPP == 0) st.enter_phase();
+      // A operands of the next k-step in front of this k-step's four MFMAs (as the one-group prefetch path)
+      AFrag nxt[2];
+      const int v = u + 2;
+      const char* src = (v < TOTAL) ? ((v / UPP == u / UPP) ? st.c_base : st.n_base) + (v % UPP) * UB
+                                    : st.n_base + (v - TOTAL) * UB;
+      load_afrag<PREC>(src, nxt[0]);
+      load_afrag<PREC>(src + UB, nxt[1]);
+      a00 = mfma16<F16>(ring.cur[0].hi, x0.hi, a00);
+      a10 = mfma16<F16>(ring.cur[0].hi, x1.hi, a10);
+      a01 = mfma16<F16>(ring.cur[1].hi, x0.hi, a01);
+      a11 = mfma16<F16>(ring.cur[1].hi, x1.hi, a11);
+      ring.cur[0] = nxt[0];
+      ring.cur[1] = nxt[1];
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS reads
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    pair_epilogue<PREC, NP_OUT, EPI>(net, tp, a00, a01, out0, heads0, g, hk);
+    pair_epilogue<PREC, NP_OUT, EPI>(net, tp, a10, a11, out1, heads1, g, hk);
+  }
+}
+
+// Whole network for one tile of 256 samples (two groups per wave); src0 / src1 supply this lane's sample of each group.
+template <int NT, int PREC, bool FULL, class Src>
+__device__ __forceinline__ void mlp_tile2(WStream& st, const NetDev& net, const Src& src0, const Src& src1, ARing& ring,
+                                          float (&sigma)[2], float (&rgb)[2][3]) {
+  constexpr int NA = NT;
+  constexpr bool F16 = PREC >= 2;
+  const int g = (threadIdx.x >> 4) & 3;
+  constexpr int D = 32 * NT;
+  const int L = net.n_layers;
+  const float* misc = net.aux + (L + 5) * D;
+  Frag A0[NA], A1[NA], B0[NA], B1[NA];
+  Frag none[1];
+  Heads h0{0.f, {0.f, 0.f, 0.f}, 0u}, h1{0.f, {0.f, 0.f, 0.f}, 0u};
+  auto enc_pos = [&](Frag (&p0)[kKsPos], Frag (&p1)[kKsPos]) __attribute__((always_inline)) {
+    float x, y, z;
+    src0.pos(x, y, z);
+    encode<kKsPos, F16, false, false>(x, y, z, net.n_freqs_pos, misc + 4, net.pos_mask, g, p0);
+    src1.pos(x, y, z);
+    encode<kKsPos, F16, false, false>(x, y, z, net.n_freqs_pos, misc + 4, net.pos_mask, g, p1);
+  };
+  {
+    Frag p0[kKsPos], p1[kKsPos];
+    enc_pos(p0, p1);
+    gemm_layer2<PREC, NT, 0, kKsPos, EPI_RELU_CVT>(st, net, 0, none, none, p0, p1, A0, A1, h0, h1, ring, g);
+  }
+#define FSN_HIDDEN2(EPI, I0, I1, O0, O1, LIDX)                                                              \
+  do {                                                                                                      \
+    if ((net.skip_mask >> ((LIDX)-1)) & 1u) {                                                               \
+      Frag p0[kKsPos], p1[kKsPos];                                                                          \
+      enc_pos(p0, p1);                                                                                      \
+      gemm_layer2<PREC, NT, NA, kKsPos, EPI>(st, net, (LIDX)*D, I0, I1, p0, p1, O0, O1, h0, h1, ring, g);    \
+    } else                                                                                                  \
+      gemm_layer2<PREC, NT, NA, 0, EPI>(st, net, (LIDX)*D, I0, I1, none, none, O0, O1, h0, h1, ring, g);    \
+  } while (0)
+  for (int l = 1; l <= L - 2; l += 2) {
+    FSN_HIDDEN2(EPI_RELU_CVT, A0, A1, B0, B1, l);
+    if (l + 1 <= L - 2) {
+      FSN_HIDDEN2(EPI_RELU_CVT, B0, B1, A0, A1, l + 1);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) { A0[i] = B0[i]; A1[i] = B1[i]; }
+    }
+  }
+  FSN_HIDDEN2((FULL ? EPI_LAST_FULL : EPI_LAST_DENS), A0, A1, B0, B1, L - 1);
+#undef FSN_HIDDEN2
+  {
+    float s0 = h0.sigma, s1 = h1.sigma;
+    s0 += __shfl_xor(s0, 16, 64); s1 += __shfl_xor(s1, 16, 64);
+    s0 += __shfl_xor(s0, 32, 64); s1 += __shfl_xor(s1, 32, 64);
+    sigma[0] = s0 + misc[0];
+    sigma[1] = s1 + misc[0];
+  }
+  if (FULL) {
+    gemm_layer2<PREC, NT, NA, 0, EPI_CVT>(st, net, L * D, B0, B1, none, none, A0, A1, h0, h1, ring, g);
+    Frag d0[kKsDir], d1[kKsDir];
+    float x, y, z;
+    src0.dir(x, y, z);
+    encode<kKsDir, F16, false, false>(x, y, z, net.n_freqs_dir, misc + 20, net.dir_mask, g, d0);
+    src1.dir(x, y, z);
+    encode<kKsDir, F16, false, false>(x, y, z, net.n_freqs_dir, misc + 20, net.dir_mask, g, d1);
+    gemm_layer2<PREC, NT / 2, NA, kKsDir, EPI_RGB>(st, net, (L + 1) * D, A0, A1, d0, d1, B0, B1, h0, h1, ring, g);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float z0 = h0.rgb[c], z1 = h1.rgb[c];
+      z0 += __shfl_xor(z0, 16, 64); z1 += __shfl_xor(z1, 16, 64);
+      z0 += __shfl_xor(z0, 32, 64); z1 += __shfl_xor(z1, 32, 64);
+      rgb[0][c] = 1.0f / (1.0f + expf(-(z0 + misc[1 + c])));
+      rgb[1][c] = 1.0f / (1.0f + expf(-(z1 + misc[1 + c])));
+    }
+  }
+  if constexpr (F16) {
+    asm("v_pk_max_u16 %0, %0, %1" : "+v"(h0.fmax) : "v"(h1.fmax));
+    range_report(net.status, h0.fmax);
+  }
+}
+
 // A-operand pair primed for the very first GEMM of a kernel (after WStream::init opened phase 0)
 template <int PREC, int NT = 0>
 __device__ __forceinline__ void prime_ring(const WStream& st, ARing& ring) {

@@ -26,9 +26,14 @@
 
 namespace fsn {
 
-constexpr int kMaxGroupSamples = 384;  // G * (S + n_imp) <= this
+constexpr int kMaxGroupSamples = 768;  // G * (S + n_imp) <= this (384 with one sample group per wave)
 constexpr int kMaxRaySamples = 384;    // S + n_imp <= this
 constexpr int kMaxG = 4;
+// sample groups of 16 per wave: 2 in the single-pass modes of 256-wide networks (mlp_dev.hpp gemm_layer2), so that a
+// workgroup tile is 256 samples and every weight phase - one barrier, one round of LDS-DMA, 16 KiB from L2 - is used
+// by twice as many samples
+template <int NT, int PREC>
+constexpr int groups_per_wave() { return ((PREC & 1) == 1 && NT == 8) ? 2 : 1; }
 
 struct RenderKArgs {
   NetParams netC, netF;
@@ -122,6 +127,7 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
             k.netF.blob + k.netF.stream_off, (uint32_t)k.netF.nph_full, repF);
   }
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  constexpr int NG = groups_per_wave<NT, PREC>(), TILE = 128 * NG;
   ARing ring;
   prime_ring<PREC, NT>(st, ring);
   // ---- the steps of one ray group (G rays), as the kernel strings them together below
@@ -155,13 +161,24 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
     if (!GRP_HIER) return;
     st.pass_begin();
     for (int sub = 0; sub < S_.nsubC; ++sub) {
-      const int idx = sub * 128 + wave * 16 + (lane & 15);
-      const int idc = min(idx, GRP_G * GRP_S - 1);
-      const int g = idc / GRP_S, i = idc - g * GRP_S;
-      const RaySrc src{S_.rays + 6 * g, S_.edgesC + g * (GRP_S + 1) + i};
-      float sigma, rgb[3];
-      mlp_tile<NT, PREC, false>(st, netC, src, ring, sigma, rgb);
-      if (lane < 16 && idx < GRP_G * GRP_S) S_.sigC[idx] = sigma;
+      // sample slot of this lane in group q of its wave
+      auto slot = [&](int q) { return sub * TILE + (wave * NG + q) * 16 + (lane & 15); };
+      auto source = [&](int idx) {
+        const int idc = min(idx, GRP_G * GRP_S - 1);
+        const int g = idc / GRP_S, i = idc - g * GRP_S;
+        return RaySrc{S_.rays + 6 * g, S_.edgesC + g * (GRP_S + 1) + i};
+      };
+      if constexpr (NG == 1) {
+        const int idx = slot(0);
+        float sigma, rgb[3];
+        mlp_tile<NT, PREC, false>(st, netC, source(idx), ring, sigma, rgb);
+        if (lane < 16 && idx < GRP_G * GRP_S) S_.sigC[idx] = sigma;
+      } else {
+        float sigma[2], rgb[2][3];
+        mlp_tile2<NT, PREC, false>(st, netC, source(slot(0)), source(slot(1)), ring, sigma, rgb);
+        const int q = (lane >> 4) & 1, idx = slot(q);  // lanes 0-15 store group 0, lanes 16-31 group 1
+        if (lane < 32 && idx < GRP_G * GRP_S) S_.sigC[idx] = sigma[q];
+      }
     }
     st.pass_end();
     lds_barrier();
@@ -182,17 +199,32 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
   auto fine_stage = [&](int64_t r0, const float* edges, bool write_edges) __attribute__((always_inline)) {
     st.pass_begin();
     for (int sub = 0; sub < S_.nsubF; ++sub) {
-      const int idx = sub * 128 + wave * 16 + (lane & 15);
-      const int idc = min(idx, GRP_G * GRP_SO - 1);
-      const int g = idc / GRP_SO, i = idc - g * GRP_SO;
-      const RaySrc src{S_.rays + 6 * g, edges + g * (GRP_SO + 1) + i};
-      float sigma, rgb[3];
-      mlp_tile<NT, PREC, true>(st, netF, src, ring, sigma, rgb);
-      if (lane < 16 && idx < GRP_G * GRP_SO) {
-        S_.sigF[idx] = sigma;
-        S_.rgbF[3 * idx + 0] = rgb[0];
-        S_.rgbF[3 * idx + 1] = rgb[1];
-        S_.rgbF[3 * idx + 2] = rgb[2];
+      auto slot = [&](int q) { return sub * TILE + (wave * NG + q) * 16 + (lane & 15); };
+      auto source = [&](int idx) {
+        const int idc = min(idx, GRP_G * GRP_SO - 1);
+        const int g = idc / GRP_SO, i = idc - g * GRP_SO;
+        return RaySrc{S_.rays + 6 * g, edges + g * (GRP_SO + 1) + i};
+      };
+      if constexpr (NG == 1) {
+        const int idx = slot(0);
+        float sigma, rgb[3];
+        mlp_tile<NT, PREC, true>(st, netF, source(idx), ring, sigma, rgb);
+        if (lane < 16 && idx < GRP_G * GRP_SO) {
+          S_.sigF[idx] = sigma;
+          S_.rgbF[3 * idx + 0] = rgb[0];
+          S_.rgbF[3 * idx + 1] = rgb[1];
+          S_.rgbF[3 * idx + 2] = rgb[2];
+        }
+      } else {
+        float sigma[2], rgb[2][3];
+        mlp_tile2<NT, PREC, true>(st, netF, source(slot(0)), source(slot(1)), ring, sigma, rgb);
+        const int q = (lane >> 4) & 1, idx = slot(q);
+        if (lane < 32 && idx < GRP_G * GRP_SO) {
+          S_.sigF[idx] = sigma[q];
+          S_.rgbF[3 * idx + 0] = rgb[q][0];
+          S_.rgbF[3 * idx + 1] = rgb[q][1];
+          S_.rgbF[3 * idx + 2] = rgb[q][2];
+        }
       }
     }
     st.pass_end();
@@ -273,7 +305,18 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
 #undef GRP_R
 
 template <int NT, int PREC>
-static int launch_render(const RenderKArgs& k, int cus, hipStream_t s) {
+static int launch_render(RenderKArgs k, int cus, hipStream_t s) {
+  // rays per workgroup group: as many as fill one tile of the coarse pass, within the LDS arrays
+  constexpr int NG = groups_per_wave<NT, PREC>(), TILE = 128 * NG, CAP = NG == 1 ? 384 : kMaxGroupSamples;
+  const int So = k.a.S + k.a.n_imp;
+  int g = TILE / k.a.S;
+  if (g < 1) g = 1;
+  if (g > CAP / So) g = CAP / So;
+  if (g > kMaxG) g = kMaxG;
+  if (g < 1) g = 1;
+  k.G = g;
+  k.nsubC = (g * k.a.S + TILE - 1) / TILE;
+  k.nsubF = (g * So + TILE - 1) / TILE;
   const int64_t ngroups = (k.a.R + k.G - 1) / k.G;
   const unsigned grid = (unsigned)(ngroups < cus ? ngroups : cus);
   // (two instantiations: the two-phase variant's second copy of both MLP passes costs registers and code the usual
@@ -342,14 +385,7 @@ extern "C" int fsn_render_rays_fused(const fsn_mlp_desc* desc, int prec, const v
   k.netF = net_params(*desc, G, blob_fine, a.status);
   k.netC = net_params(*desc, G, a.n_imp > 0 ? blob_coarse : blob_fine, a.status);
   k.a = a;
-  int g = 128 / a.S;
-  if (g < 1) g = 1;
-  if (g > kMaxGroupSamples / So) g = kMaxGroupSamples / So;
-  if (g > kMaxG) g = kMaxG;
-  if (g < 1) g = 1;
-  k.G = g;
-  k.nsubC = (g * a.S + 127) / 128;
-  k.nsubF = (g * So + 127) / 128;
+  k.G = k.nsubC = k.nsubF = 0;  // (set per instantiation in launch_render: the tile is 128 or 256 samples)
   k.step = (float)(((double)a.far - (double)a.near) / a.S);
   k.two_phase = (a.two_phase && a.n_imp > 0 && a.edges_out) ? 1 : 0;
   k.cam_hw = (float)(a.cam_W * 0.5);
