@@ -68,7 +68,9 @@ constexpr int kLook = kLead > 0 ? kNSlot - 2 - kLag : kNSlot - 1;
 // moment; now the partner wave of each loader (w + 4) runs its MFMAs meanwhile.
 constexpr int kLoaders = 4;
 constexpr int kOpenVmcnt = (kLook - 1 - kLag) * (kPhaseBytes / 1024 / kLoaders);
+#ifndef FSN_RING_EXPERIMENT  // (timing experiments with other ring depths: compiler-scheduled paths only)
 static_assert(kOpenVmcnt == 4, "the generated k-loop blocks wait with vmcnt(4)");
+#endif
 __device__ __forceinline__ uint32_t slot_add(uint32_t s, uint32_t k) {  // (s + k) mod kNSlot, s < kNSlot, k <= kNSlot
   if ((kNSlot & (kNSlot - 1)) == 0) return (s + k) & (kNSlot - 1);
   const uint32_t t = s + k;
@@ -379,7 +381,18 @@ __device__ __forceinline__ void encode(float x0, float x1, float x2, int n_freqs
     const int coord = ps - 3 * band;
     const float xc = coord == 0 ? x0 : (coord == 1 ? x1 : x2);
     float s, c;
-    sincos_f32(xc * freqs[band], s, c);
+    if constexpr (X3) {
+      sincos_f32(xc * freqs[band], s, c);
+    } else {
+      // single-pass modes: the features are rounded to 16 bits (relative 2^-9 / 2^-12) right below, so the hardware
+      // sine / cosine of the reduced argument is exact enough: argument in revolutions, reduced by v_fract
+      // (absolute error <= |arg| 6e-8 / 2pi revolutions, ~1e-4 rad at the highest frequency), 5 instructions
+      // instead of ~30 per pair.  The x3 (parity) modes never take this branch.
+      const float rev = (xc * freqs[band]) * 0.15915494309189535f;
+      const float fr = __builtin_amdgcn_fractf(rev);
+      s = __builtin_amdgcn_sinf(fr);
+      c = __builtin_amdgcn_cosf(fr);
+    }
     v[2 * i] = ok ? s * mask[3 + band * 6 + coord] : 0.f;
     v[2 * i + 1] = ok ? c * mask[3 + band * 6 + 3 + coord] : 0.f;
   }
@@ -525,6 +538,21 @@ __device__ __forceinline__ void pair_epilogue(const NetDev& net, int tp, const f
     float v[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { v[j] = acc0[j]; v[4 + j] = acc1[j]; }
+    if constexpr (!X3 && EPI == EPI_RELU_CVT && std::is_same<HK, NoHook>::value) {
+      // single-pass modes: convert first, ReLU on the packed 16-bit values (sign bit = top bit of either format, so a
+      // signed 16-bit max with 0 is the ReLU; rounding keeps the sign, so relu(round(x)) == round(relu(x))):
+      // 4 + 4 instructions per pair instead of 8 + 4
+      Frag& o = out[tp < NOUT ? tp : 0];
+      split_store<F16, false>(v, o);
+      typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+      u32x4 w = __builtin_bit_cast(u32x4, o.hi);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm("v_pk_max_i16 %0, %0, 0" : "+v"(w[i]));
+      o.hi = __builtin_bit_cast(s16x8, w);
+      if constexpr (F16) range_track<false>(heads.fmax, o.hi);
+      asm volatile("" : "+v"(o.hi));
+      return;
+    }
     if (EPI != EPI_CVT && EPI != EPI_NONE) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = relu_f32(v[j]);
@@ -935,6 +963,31 @@ __device__ __forceinline__ void gemm_layer2(WStream& st, const NetDev& net, int 
   static_assert(KS_ACT <= NACT && KS_ENC <= NENC, "operand arrays too small");
   const float* bias = net.aux + aux_bias;
   NoHook hk;
+  // EPI_RELU_CVT: the conversion of pair tp-1 (two groups x four dwords: one packed convert + one packed ReLU each) is
+  // spread over the k-steps of pair tp, one dword per k-step, so that it issues beside the MFMAs instead of behind
+  // them with both waves of the SIMD converting at the same time.  (The single-pass modes have the issue slots for it:
+  // 8 + 4 of 16 cycles per MFMA; the x3 modes do not)
+  constexpr bool PIPE = EPI == EPI_RELU_CVT && KS >= 8;
+  f32x4 p00, p01, p10, p11;  // accumulators of the previous pair, [group][tile]
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+  u32x4 w0, w1;
+  auto cvt_dword = [&](int d) __attribute__((always_inline)) {  // dword d (0..7) of the previous pair: group d>>2
+    const f32x4& t = (d >> 2) ? ((d & 2) ? p11 : p10) : ((d & 2) ? p01 : p00);
+    const float x = t[2 * (d & 1)], y = t[2 * (d & 1) + 1];
+    uint32_t r;  // (asm: hipcc converts the two halves separately and merges them with shifts otherwise; the inputs
+    // are results of MFMAs at least two MFMAs back, so the unpadded XDL-write -> VALU-read hazard cannot bite)
+    if constexpr (F16) asm("v_cvt_pk_f16_f32 %0, %1, %2\n\tv_pk_max_i16 %0, %0, 0" : "=v"(r) : "v"(x), "v"(y));
+    else asm("v_cvt_pk_bf16_f32 %0, %1, %2\n\tv_pk_max_i16 %0, %0, 0" : "=v"(r) : "v"(x), "v"(y));
+    if (d >> 2) w1[d & 3] = r; else w0[d & 3] = r;
+  };
+  auto finish_prev = [&](int tpp) __attribute__((always_inline)) {
+    out0[tpp < NOUT ? tpp : 0].hi = __builtin_bit_cast(s16x8, w0);
+    out1[tpp < NOUT ? tpp : 0].hi = __builtin_bit_cast(s16x8, w1);
+    if constexpr (F16) {
+      range_track<false>(heads0.fmax, out0[tpp < NOUT ? tpp : 0].hi);
+      range_track<false>(heads1.fmax, out1[tpp < NOUT ? tpp : 0].hi);
+    }
+  };
 #pragma unroll
   for (int tp = 0; tp < NP_OUT; ++tp) {
     const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + 32 * tp + 4 * g);
@@ -958,14 +1011,31 @@ __device__ __forceinline__ void gemm_layer2(WStream& st, const NetDev& net, int 
       a10 = mfma16<F16>(ring.cur[0].hi, x1.hi, a10);
       a01 = mfma16<F16>(ring.cur[1].hi, x0.hi, a01);
       a11 = mfma16<F16>(ring.cur[1].hi, x1.hi, a11);
+      const bool conv = PIPE && tp > 0 && ks < 8;
+      if (conv) cvt_dword(ks);
       ring.cur[0] = nxt[0];
       ring.cur[1] = nxt[1];
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS reads
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // MFMAs
+      if (conv) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);  // MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);  // convert + packed ReLU (one asm statement)
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // MFMAs
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
-    pair_epilogue<PREC, NP_OUT, EPI>(net, tp, a00, a01, out0, heads0, g, hk);
-    pair_epilogue<PREC, NP_OUT, EPI>(net, tp, a10, a11, out1, heads1, g, hk);
+    if constexpr (PIPE) {
+      if (tp > 0) finish_prev(tp - 1);
+      p00 = a00; p01 = a01; p10 = a10; p11 = a11;
+      if (tp == NP_OUT - 1) {  // the last pair converts on its own (compiler-padded form)
+        pair_epilogue<PREC, NP_OUT, EPI>(net, tp, a00, a01, out0, heads0, g, hk);
+        pair_epilogue<PREC, NP_OUT, EPI>(net, tp, a10, a11, out1, heads1, g, hk);
+      }
+    } else {
+      pair_epilogue<PREC, NP_OUT, EPI>(net, tp, a00, a01, out0, heads0, g, hk);
+      pair_epilogue<PREC, NP_OUT, EPI>(net, tp, a10, a11, out1, heads1, g, hk);
+    }
   }
 }
 
