@@ -963,31 +963,6 @@ __device__ __forceinline__ void gemm_layer2(WStream& st, const NetDev& net, int 
   static_assert(KS_ACT <= NACT && KS_ENC <= NENC, "operand arrays too small");
   const float* bias = net.aux + aux_bias;
   NoHook hk;
-  // EPI_RELU_CVT: the conversion of pair tp-1 (two groups x four dwords: one packed convert + one packed ReLU each) is
-  // spread over the k-steps of pair tp, one dword per k-step, so that it issues beside the MFMAs instead of behind
-  // them with both waves of the SIMD converting at the same time.  (The single-pass modes have the issue slots for it:
-  // 8 + 4 of 16 cycles per MFMA; the x3 modes do not)
-  constexpr bool PIPE = EPI == EPI_RELU_CVT && KS >= 8;
-  f32x4 p00, p01, p10, p11;  // accumulators of the previous pair, [group][tile]
-  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-  u32x4 w0, w1;
-  auto cvt_dword = [&](int d) __attribute__((always_inline)) {  // dword d (0..7) of the previous pair: group d>>2
-    const f32x4& t = (d >> 2) ? ((d & 2) ? p11 : p10) : ((d & 2) ? p01 : p00);
-    const float x = t[2 * (d & 1)], y = t[2 * (d & 1) + 1];
-    uint32_t r;  // (asm: hipcc converts the two halves separately and merges them with shifts otherwise; the inputs
-    // are results of MFMAs at least two MFMAs back, so the unpadded XDL-write -> VALU-read hazard cannot bite)
-    if constexpr (F16) asm("v_cvt_pk_f16_f32 %0, %1, %2\n\tv_pk_max_i16 %0, %0, 0" : "=v"(r) : "v"(x), "v"(y));
-    else asm("v_cvt_pk_bf16_f32 %0, %1, %2\n\tv_pk_max_i16 %0, %0, 0" : "=v"(r) : "v"(x), "v"(y));
-    if (d >> 2) w1[d & 3] = r; else w0[d & 3] = r;
-  };
-  auto finish_prev = [&](int tpp) __attribute__((always_inline)) {
-    out0[tpp < NOUT ? tpp : 0].hi = __builtin_bit_cast(s16x8, w0);
-    out1[tpp < NOUT ? tpp : 0].hi = __builtin_bit_cast(s16x8, w1);
-    if constexpr (F16) {
-      range_track<false>(heads0.fmax, out0[tpp < NOUT ? tpp : 0].hi);
-      range_track<false>(heads1.fmax, out1[tpp < NOUT ? tpp : 0].hi);
-    }
-  };
 #pragma unroll
   for (int tp = 0; tp < NP_OUT; ++tp) {
     const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + 32 * tp + 4 * g);
@@ -1011,31 +986,18 @@ __device__ __forceinline__ void gemm_layer2(WStream& st, const NetDev& net, int 
       a10 = mfma16<F16>(ring.cur[0].hi, x1.hi, a10);
       a01 = mfma16<F16>(ring.cur[1].hi, x0.hi, a01);
       a11 = mfma16<F16>(ring.cur[1].hi, x1.hi, a11);
-      const bool conv = PIPE && tp > 0 && ks < 8;
-      if (conv) cvt_dword(ks);
       ring.cur[0] = nxt[0];
       ring.cur[1] = nxt[1];
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS reads
-      if (conv) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);  // MFMAs
-        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);  // convert + packed ReLU (one asm statement)
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      } else {
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // MFMAs
-      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // MFMAs
       __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (PIPE) {
-      if (tp > 0) finish_prev(tp - 1);
-      p00 = a00; p01 = a01; p10 = a10; p11 = a11;
-      if (tp == NP_OUT - 1) {  // the last pair converts on its own (compiler-padded form)
-        pair_epilogue<PREC, NP_OUT, EPI>(net, tp, a00, a01, out0, heads0, g, hk);
-        pair_epilogue<PREC, NP_OUT, EPI>(net, tp, a10, a11, out1, heads1, g, hk);
-      }
-    } else {
-      pair_epilogue<PREC, NP_OUT, EPI>(net, tp, a00, a01, out0, heads0, g, hk);
-      pair_epilogue<PREC, NP_OUT, EPI>(net, tp, a10, a11, out1, heads1, g, hk);
-    }
+    // (Issuing the conversion of pair tp-1 beside pair tp's MFMAs - one packed convert + ReLU per k-step, as inline
+    // asm - gained 0.9 % and was NOT safe: hipcc does not see the XDL hazards of registers an asm statement touches,
+    // and the bf16 density pass came out different from run to run.  tests/test_parity_fp64.py now renders the
+    // same rays alone and inside a frame in this mode too.)
+    pair_epilogue<PREC, NP_OUT, EPI>(net, tp, a00, a01, out0, heads0, g, hk);
+    pair_epilogue<PREC, NP_OUT, EPI>(net, tp, a10, a11, out1, heads1, g, hk);
   }
 }
 

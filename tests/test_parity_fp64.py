@@ -313,6 +313,85 @@ def test_config5_single_pass_vs_rounding_emulating_oracle(dev, prec):
     assert float((rgb.cpu() - o32[0][0]).abs().max()) <= {"bf16": 2e-3, "fp16": 3e-4}[prec] * 4
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_single_pass_two_groups_per_wave_ragged_shapes(dev, prec):
+    """The single-pass modes of 256-wide networks run 32 samples per wave in 256-sample tiles (two 16-sample groups
+    sharing every weight operand): sizes that end inside a group, a wave or a tile, ray counts below the rays of one
+    workgroup, sample counts that do not divide the tile - each against the rounding-emulating oracle."""
+    from fs_nerf_amd.render import rendering as Rm
+    L, D = 8, 256
+    sd = make_sd(L, D, 42)
+    m = hip_model(sd, L, D, dev, prec)
+    tol = {"bf16": 2e-3, "fp16": 3e-4}[prec]
+    gen = torch.Generator().manual_seed(11)
+    for n in (1, 15, 17, 255, 256, 257, 700):
+        x = torch.rand(n, 3, generator=gen) * 3 - 1.5
+        dv = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1)
+        with torch.no_grad():
+            y4 = m(x.to(dev), dv.to(dev)).cpu()
+            y1 = m(x.to(dev)).cpu()
+            y4b, y1b = m(x.to(dev), dv.to(dev)).cpu(), m(x.to(dev)).cpu()
+        assert torch.equal(y4, y4b) and torch.equal(y1, y1b), f"n={n}: not reproducible from launch to launch"
+        e4 = O.nerf_forward(sd, x, dv, emulate=prec, **cfg_of(L))
+        assert y4.shape == (n, 4) and y1.shape == (n, 1)
+        # rgb in [0,1]: tol.  sigma: the test nets' density head has a x64 gain, so one flipped 16-bit rounding of a
+        # hidden activation moves it by up to ~16 tol (its effect on a weight, sigma x interval length, is what the
+        # render checks below and the config-5 test bound by tol)
+        assert float((y4[:, :3] - e4[:, :3]).abs().max()) <= tol, f"n={n} rgb"
+        assert float((y4[:, 3] - e4[:, 3]).abs().max()) <= 16 * tol, f"n={n} sigma"
+        assert float((y1[:, 0] - e4[:, 3]).abs().max()) <= 16 * tol, f"n={n} density-only pass"
+        assert float((y1[:, 0] - y4[:, 3]).abs().max()) == 0.0, f"n={n} density-only pass == full pass sigma"
+    sd_f = make_sd(L, D, 43)
+    mf = hip_model(sd_f, L, D, dev, prec)
+    for R, S, NI in ((1, 64, 128), (3, 96, 32), (5, 128, 256), (7, 40, 0), (9, 200, 56)):
+        o, d, _ = orbit_rays(R, 3 + R, 400, 555.5)
+        est = Rm.StratifiedEstimator(2.0, 6.0, S, NI)
+        with torch.no_grad():
+            (rgb, op, dep, ex), _, _ = Rm.render_rays(o, d, est, m, white_bkgd=True, device=dev, model_fine=mf if NI else None)
+        kw = dict(near=2.0, far=6.0, n_samples=S, n_importance=NI, white_bkgd=True, emulate=prec)
+        emu = O.render_rays_oracle(o, d, sd, sd_f if NI else None, cfg_of(L), edges_override=ex["edges"].cpu() if NI else None, **kw)
+        what = f"R={R} S={S} NI={NI}"
+        assert float((rgb.cpu() - emu[0][0]).abs().max()) <= tol, what + " rgb_map"
+        assert float((op.cpu() - emu[0][1]).abs().max()) <= tol, what + " opacity"
+        assert float((ex["weights"].cpu().reshape(R, -1) - emu[0][3]["weights"]).abs().max()) <= tol, what + " weights"
+
+
+def test_config5_full_frame_1600_properties(dev):
+    """BASELINE configs[4] at full size: 1600x1600, 128+256 samples, two 8x256 networks in bf16, one fused launch with
+    the rays generated in it.  Size-independent properties on all 2,560,000 rays; 48 of them re-rendered alone must
+    reproduce their pixels bit for bit and agree with the rounding-emulating oracle."""
+    from fs_nerf_amd.render import rendering as Rm
+    L, D, S, NI = 8, 256, 128, 256
+    sd_c, sd_f = make_sd(L, D, 42), make_sd(L, D, 43)
+    mc, mf = hip_model(sd_c, L, D, dev, "bf16"), hip_model(sd_f, L, D, dev, "bf16")
+    est = Rm.StratifiedEstimator(2.0, 6.0, S, NI)
+    pose = O.pose_from_spherical(4.0311289, 50.0, 77.0)
+    hwf = (1600, 1600, 0.5 * 1600 / np.tan(0.5 * 0.6911112))
+    with torch.no_grad():
+        img, depth = Rm.render_frame(hwf, 2.0, 6.0, pose, 1 << 30, est, mc, white_bkgd=True, device=dev, model_fine=mf)
+    assert img.shape == (1600, 1600, 3) and depth.shape == (1600, 1600)
+    assert bool(torch.isfinite(img).all()) and bool(torch.isfinite(depth).all())
+    assert float(depth.min()) >= 2.0 and float(depth.max()) <= 6.0
+    assert float(img.min()) >= 0.0 and float(img.max()) <= 1.0 + 1e-6
+    o, d = Rm.U.get_rays(pose, hwf, dev)
+    o, d = o.reshape(-1, 3), d.reshape(-1, 3)
+    idx = torch.randperm(1600 * 1600, generator=torch.Generator().manual_seed(2))[:48].to(dev)
+    with torch.no_grad():
+        (rgb, op, dep, ex), _, _ = Rm.render_rays(o[idx], d[idx], est, mc, white_bkgd=True, device=dev, model_fine=mf)
+    assert torch.equal(rgb, img.reshape(-1, 3)[idx]), "a ray renders the same alone and inside the frame"
+    assert torch.equal(dep.reshape(-1).clamp(2.0, 6.0), depth.reshape(-1)[idx])
+    with torch.no_grad():
+        img2, _ = Rm.render_frame(hwf, 2.0, 6.0, pose, 1 << 30, est, mc, white_bkgd=True, device=dev, model_fine=mf)
+    assert torch.equal(img, img2), "reproducible from launch to launch"
+    w = ex["weights"].reshape(48, S + NI)
+    assert float((w.sum(-1, keepdim=True) - op).abs().max()) < 1e-5, "opacity = sum of weights"
+    assert bool((ex["edges"][:, 1:] >= ex["edges"][:, :-1]).all()), "sorted sample union"
+    kw = dict(near=2.0, far=6.0, n_samples=S, n_importance=NI, white_bkgd=True, emulate="bf16")
+    emu = O.render_rays_oracle(o[idx].cpu(), d[idx].cpu(), sd_c, sd_f, cfg_of(L), edges_override=ex["edges"].cpu(), **kw)
+    assert float((rgb.cpu() - emu[0][0]).abs().max()) <= 2e-3, "rgb_map vs the emulating oracle"
+    assert float((w.cpu() - emu[0][3]["weights"]).abs().max()) <= 2e-3, "weights vs the emulating oracle"
+
+
 # ------------------------------------------------------------------ the headline configuration at full size
 def test_full_frame_800_two_8x256_properties_and_parity(dev):
     """BASELINE configs[2] as bench.py runs it: an 800x800 frame, 64+128 samples, TWO 8x256 networks, one fused launch.
