@@ -35,7 +35,9 @@ typedef void* fsn_stream_t; /* hipStream_t */
 
 /* arithmetic of the MLP contractions */
 #define FSN_PREC_BF16X3 0 /* split-bf16 (hi+lo) x 3 MFMA passes, fp32 accumulate: ~1e-5 relative per product */
-#define FSN_PREC_BF16 1   /* single bf16 MFMA pass, fp32 accumulate (BASELINE config 5) */
+#define FSN_PREC_BF16 1   /* single bf16 MFMA pass, fp32 accumulate (BASELINE config 5).  The single-pass modes round
+                             every operand to 16 bits and evaluate the encodings' sines with the hardware
+                             instruction (|err| ~1e-4 rad, below that rounding) */
 #define FSN_PREC_FP16X3 2 /* split-fp16 (hi+lo) x 3 MFMA passes: fp32-grade accuracy; |activation| must stay
                              below 65504 (fp16 range) - the default "parity" mode */
 #define FSN_PREC_FP16 3   /* single fp16 MFMA pass */
