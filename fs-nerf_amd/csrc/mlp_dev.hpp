@@ -364,11 +364,11 @@ __device__ __forceinline__ void sincos_f32(float a, float& s_out, float& c_out) 
 // Slot layout = enc_slot_feature() in mlp_layout.hpp; value = reference feature (models.py:37-39)
 // times the frequency mask (LDS, all ones when absent).  NKS k-steps (NKS*8 slots per lane; the
 // four lanes g = lane>>4 of a sample share the NKS*32 slots).
-// `save` (training forward only, else null): this lane's column of the encoding's T-layout buffer at row 8g; slot
-// (k-step ks, element j) is stored at row 32 ks + 8 g + j, i.e. in B-operand order (train_fused.hip).
+// `save` (training forward only, else null): this lane's column of the encoding's packed T-layout buffer; slot
+// (k-step ks, element j) is row 32 ks + 8 g + j, i.e. B-operand order (train_fused.hip).
 template <int NKS, bool F16, bool X3, bool SAVE = false>
 __device__ __forceinline__ void encode(float x0, float x1, float x2, int n_freqs, const float* __restrict__ freqs,
-                                       const float* __restrict__ mask, int g, Frag (&out)[NKS], float* save = nullptr) {
+                                       const float* __restrict__ mask, int g, Frag (&out)[NKS], uint32_t* save = nullptr) {
   constexpr int SLOTS = 8 * NKS;
   float v[SLOTS];
   const int P = 3 * n_freqs;
@@ -401,12 +401,22 @@ __device__ __forceinline__ void encode(float x0, float x1, float x2, int n_freqs
     v[SLOTS - 1] = x1 * mask[1];
   }
   if (g == 3) v[SLOTS - 2] = x2 * mask[2];
-  if constexpr (SAVE) {
-#pragma unroll
-    for (int q = 0; q < SLOTS; ++q) save[((q >> 3) * 32 + (q & 7)) * kTileCols] = v[q];
-  }
 #pragma unroll
   for (int k = 0; k < NKS; ++k) split_store<F16, X3>(&v[8 * k], out[k]);
+  if constexpr (SAVE) {
+    // packed T-layout (train_fused.hip): slots (k, 2i), (k, 2i+1) are rows 32k + 8g + 2i, +1 = pair-row 16k + 4g + i;
+    // `save` = this lane's column at pair-row 4g of the high-part plane, the low-part plane 16 NKS pair-rows further
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+#pragma unroll
+    for (int k = 0; k < NKS; ++k) {
+      const u32x4 h = __builtin_bit_cast(u32x4, out[k].hi), l = __builtin_bit_cast(u32x4, out[k].lo);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_nontemporal_store(h[i], save + (16 * k + i) * kTileCols);
+        if (X3) __builtin_nontemporal_store(l[i], save + (16 * NKS + 16 * k + i) * kTileCols);
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------- one GEMM layer
@@ -519,6 +529,7 @@ __device__ __forceinline__ float relu_f32(float v) {  // on the sign bit: one v_
 // Inference uses NoHook (no code); the training kernels (train_fused.hip) save / mask / store there.
 struct NoHook {
   static constexpr bool kZeroInit = false;  // accumulators start from the bias
+  static constexpr bool kPacked = false;    // no store<X3>(tp, frag) of the pair's 16-bit parts (training savers: true)
   __device__ __forceinline__ void pre(int) {}
   __device__ __forceinline__ void post(int, float (&)[8]) {}
 };
@@ -601,6 +612,17 @@ __device__ __forceinline__ void pair_epilogue(const NetDev& net, int tp, const f
 #endif
       if (X3) asm volatile("" : "+v"(o.hi), "+v"(o.lo));
       else asm volatile("" : "+v"(o.hi));
+    }
+    // training savers keep the pair's 16-bit high / low parts (the operands the weight-gradient GEMM consumes), not
+    // the fp32 values: where the epilogue has just formed them for the next layer they cost nothing extra
+    if constexpr (HK::kPacked) {
+      if constexpr (EPI == EPI_RELU_CVT || EPI == EPI_CVT || EPI == EPI_LAST_FULL) {
+        hk.template store<X3>(tp, out[tp < NOUT ? tp : 0]);
+      } else {
+        Frag t;
+        split_store_cpp<F16, X3>(v, t);
+        hk.template store<X3>(tp, t);
+      }
     }
 }
 
@@ -1111,8 +1133,8 @@ struct NoSave {
   using Hook = NoHook;
   __device__ __forceinline__ Hook hidden(int) const { return {}; }  // hidden layer l / connection (l = n_layers)
   __device__ __forceinline__ Hook branch() const { return {}; }
-  __device__ __forceinline__ float* enc_pos(int) const { return nullptr; }
-  __device__ __forceinline__ float* enc_dir(int) const { return nullptr; }
+  __device__ __forceinline__ uint32_t* enc_pos(int) const { return nullptr; }
+  __device__ __forceinline__ uint32_t* enc_dir(int) const { return nullptr; }
 };
 
 template <int NT, int PREC, bool FULL, class Src, class SV>

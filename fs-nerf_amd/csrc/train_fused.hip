@@ -12,9 +12,14 @@
 //                   (deterministic) by k_wgrad_reduce, which also undoes the slot permutation of the encodings.
 //   k_heads_wgrad : sigma / rgb head weights (1 and 3 output rows): HBM-bound row dot products.
 //
-// "T-layout" of every saved matrix: tiles of 128 samples (one workgroup tile), [tile][row = feature][128 samples]
-// fp32.  It is what the accumulator layout of the transposed MLP stores with 64-byte row segments, and it makes
-// BOTH wgrad operands contiguous along the contraction (sample) axis, so they load straight into MFMA operands.
+// "Packed T-layout" of every saved matrix with R rows (features): tiles of 128 samples (one workgroup tile),
+// [tile][plane][R/2 pair-rows][128 samples] x 32 bit.  Plane 0 holds the 16-bit HIGH parts, plane 1 the LOW parts (x3
+// modes only) of the value in the mode's 16-bit format; dword (q, s) = part(row 2q, s) | part(row 2q+1, s) << 16.
+// These are the words the forward / backward epilogues form anyway for the next GEMM's B operand (a packed pair of
+// neighbouring features of one sample), so saving costs the stores only - and the weight-gradient GEMM, whose
+// contraction runs along the samples, loads 32 contiguous bytes per lane and has both rows' MFMA operands after four
+// v_perm_b32 each, instead of splitting fp32 values itself (it was bound by exactly that VALU work: 3.44 ms at
+// 3.8 TB/s before).  Same bytes as fp32 in the x3 modes, half in the single-pass modes.
 //
 // Precision: as the forward, split 16-bit x 3 passes with fp32 accumulation.  In the fp16 modes d(out) is
 // multiplied by a power-of-two `grad_scale` on entry (and the result divided by it in the reduce) so that the
@@ -24,11 +29,6 @@
 // x3 modes: pinned one-unit-ahead LDS prefetch of the A operands (mlp_dev.hpp).  +6 % on these kernels; the fused
 // render kernel keeps the compiler's own read placement (with its larger live state the pinned form spills more).
 #define FSN_X3_PF1
-// wgrad converts its operands with the compiler-scheduled C++ split: the inline-asm form (mlp_dev.hpp) cannot be
-// interleaved with the global loads and cost 30 % there (k_wgrad<4,4,2>: 4.37 ms against 3.36 ms per step)
-#ifndef FSN_WG_SPLIT
-#define FSN_WG_SPLIT split_store_cpp
-#endif
 #include "mlp_dev.hpp"
 #include "mlp_layout.hpp"
 #include "train_internal.hpp"
@@ -118,38 +118,59 @@ static int make_fused_layout(const fsn_mlp_desc& d, int prec, int64_t n, FusedLa
 #define FSN_STREAM_STORE(v, p) __builtin_nontemporal_store((v), (p))
 #endif
 
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+// Store the 16-bit parts of output pair tp (accumulator order: dword i of a part = rows 32 tp + 16 (i>>1) + 4 g +
+// 2 (i&1), +1 = pair-row 16 tp + 8 (i>>1) + 2 g + (i&1)).  p: this lane's column at pair-row 2g of the high-part
+// plane of its tile; plane: dwords between the two planes (R/2 x 128).
+template <bool X3>
+__device__ __forceinline__ void store_pair_parts(uint32_t* p, int64_t plane, int tp, const Frag& o) {
+  const u32x4 h = __builtin_bit_cast(u32x4, o.hi), l = __builtin_bit_cast(u32x4, o.lo);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint32_t* q = p + (16 * tp + 8 * (i >> 1) + (i & 1)) * kTC;
+    FSN_STREAM_STORE(h[i], q);
+    if (X3) FSN_STREAM_STORE(l[i], q + plane);
+  }
+}
+
 // ------------------------------------------------------------------ forward with saved activations
 struct FwdSaver {
   static constexpr bool kSave = true;
-  // Stores the fp32 values (T-layout) and, for ReLU layers, their sign bits: bit 8 tp + j of this lane's 64-bit
+  // Stores the 16-bit parts (packed T-layout) and, for ReLU layers, the sign bits: bit 8 tp + j of this lane's 64-bit
   // word (byte tp, bit j) <=> element j of output pair tp is > 0.  The dgrad chain reads only the bits.
   struct Hook {
     static constexpr bool kZeroInit = false;
-    float* p;
-    uint8_t* mk;  // this lane's 8 mask bytes (one per output pair), or null (layer without activation)
+    static constexpr bool kPacked = true;
+    uint32_t* p;    // this lane's column at pair-row 2g, high-part plane
+    int64_t plane;  // dwords to the low-part plane
+    uint8_t* mk;    // this lane's 8 mask bytes (one per output pair), or null (layer without activation)
     __device__ __forceinline__ void pre(int) {}
     __device__ __forceinline__ void post(int tp, float (&v)[8]) {
-      uint32_t b = 0;
+      if (mk) {
+        uint32_t b = 0;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        FSN_STREAM_STORE(v[j], p + (32 * tp + 16 * (j >> 2) + (j & 3)) * kTC);
-        b |= (v[j] > 0.f ? 1u : 0u) << j;
+        for (int j = 0; j < 8; ++j) b |= (v[j] > 0.f ? 1u : 0u) << j;
+        mk[tp] = (uint8_t)b;  // byte stores: accumulating the 64-bit word in registers tips the x3 modes into scratch
       }
-      if (mk) mk[tp] = (uint8_t)b;  // byte stores: accumulating the 64-bit word in registers tips the x3 modes into scratch
     }
+    template <bool X3>
+    __device__ __forceinline__ void store(int tp, const Frag& o) { store_pair_parts<X3>(p, plane, tp, o); }
   };
-  float* h0;  // this lane's column, row 4g, of H_0's tile
-  int64_t hstride;
-  float *bo, *pe, *de;
+  uint32_t* h0;  // this lane's column, pair-row 2g, of H_0's tile
+  int64_t hstride, hplane, boplane;
+  uint32_t *bo, *pe, *de;
   uint32_t* mk0;  // this lane's mask words of layer 0
   int64_t mstride;
   int n_layers;
   __device__ __forceinline__ Hook hidden(int l) const {
-    return Hook{h0 + l * hstride, l < n_layers ? reinterpret_cast<uint8_t*>(mk0 + l * mstride) : nullptr};
+    return Hook{h0 + l * hstride, hplane, l < n_layers ? reinterpret_cast<uint8_t*>(mk0 + l * mstride) : nullptr};
   }
-  __device__ __forceinline__ Hook branch() const { return Hook{bo, reinterpret_cast<uint8_t*>(mk0 + n_layers * mstride)}; }
-  __device__ __forceinline__ float* enc_pos(int) const { return pe; }
-  __device__ __forceinline__ float* enc_dir(int) const { return de; }
+  __device__ __forceinline__ Hook branch() const {
+    return Hook{bo, boplane, reinterpret_cast<uint8_t*>(mk0 + n_layers * mstride)};
+  }
+  __device__ __forceinline__ uint32_t* enc_pos(int) const { return pe; }
+  __device__ __forceinline__ uint32_t* enc_dir(int) const { return de; }
 };
 
 struct TrainFwdArgs {
@@ -195,11 +216,14 @@ __global__ __launch_bounds__(kThreads) void k_train_fwd(TrainFwdArgs a) {
     __builtin_amdgcn_wave_barrier();
     const TileSrcT src{in_lds + col * 6};
     FwdSaver sv;
-    sv.h0 = a.ws + a.off_h + (tile * D + 4 * g) * kTC + col;
+    uint32_t* wsu = reinterpret_cast<uint32_t*>(a.ws);
+    sv.h0 = wsu + a.off_h + (tile * D + 2 * g) * kTC + col;
     sv.hstride = a.h_stride;
-    sv.bo = a.ws + a.off_bo + (tile * (D / 2) + 4 * g) * kTC + col;
-    sv.pe = a.ws + a.off_pe + (tile * 64 + 8 * g) * kTC + col;
-    sv.de = a.ws + a.off_de + (tile * 32 + 8 * g) * kTC + col;
+    sv.hplane = (D / 2) * kTC;
+    sv.bo = wsu + a.off_bo + (tile * (D / 2) + 2 * g) * kTC + col;
+    sv.boplane = (D / 4) * kTC;
+    sv.pe = wsu + a.off_pe + (tile * 64 + 4 * g) * kTC + col;
+    sv.de = wsu + a.off_de + (tile * 32 + 4 * g) * kTC + col;
     sv.mk0 = reinterpret_cast<uint32_t*>(a.ws + a.off_mask) + ((tile * 4 + g) * kTC + col) * 2;
     sv.mstride = a.mask_stride;
     sv.n_layers = net.n_layers;
@@ -259,19 +283,22 @@ __global__ void k_pack_bwd(BwdPackArgs a, char* __restrict__ stream, int64_t n_p
 // ------------------------------------------------------------------ backward chain (dgrad)
 struct BwdStoreHook {
   static constexpr bool kZeroInit = true;
-  float* d;
+  static constexpr bool kPacked = true;
+  uint32_t* d;  // this lane's column at pair-row 2g of the gradient's high-part plane
+  int64_t plane;
   __device__ __forceinline__ void pre(int) {}
-  __device__ __forceinline__ void post(int tp, float (&v)[8]) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) FSN_STREAM_STORE(v[j], d + (32 * tp + 16 * (j >> 2) + (j & 3)) * kTC);
-  }
+  __device__ __forceinline__ void post(int, float (&)[8]) {}
+  template <bool X3>
+  __device__ __forceinline__ void store(int tp, const Frag& o) { store_pair_parts<X3>(d, plane, tp, o); }
 };
 
 template <bool ADD_SIGMA>
 struct BwdMaskHook {
   static constexpr bool kZeroInit = true;
+  static constexpr bool kPacked = true;
   uint32_t b0, b1;    // sign bits of the layer whose pre-activation gradient this is (FwdSaver::Hook)
-  float* d;           // dPre destination
+  uint32_t* d;        // dPre destination (as BwdStoreHook)
+  int64_t plane;
   float dsig;         // d sigma of this lane's sample
   const float* wsig;  // LDS: w_sigma + 4g
   __device__ __forceinline__ void pre(int) {}
@@ -287,11 +314,10 @@ struct BwdMaskHook {
     }
     const uint32_t bits = (tp < 4 ? b0 : b1) >> (8 * (tp & 3));
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      v[j] = ((bits >> j) & 1u) ? v[j] : 0.f;
-      FSN_STREAM_STORE(v[j], d + (32 * tp + 16 * (j >> 2) + (j & 3)) * kTC);
-    }
+    for (int j = 0; j < 8; ++j) v[j] = ((bits >> j) & 1u) ? v[j] : 0.f;
   }
+  template <bool X3>
+  __device__ __forceinline__ void store(int tp, const Frag& o) { store_pair_parts<X3>(d, plane, tp, o); }
 };
 
 struct TrainBwdArgs {
@@ -341,13 +367,15 @@ __global__ __launch_bounds__(kThreads) void k_train_bwd(TrainBwdArgs a) {
       float* dh = a.ws + a.off_dhead + tile * 4 * kTC + col;
       dh[0] = dz[0]; dh[kTC] = dz[1]; dh[2 * kTC] = dz[2]; dh[3 * kTC] = dsig;
     }
-    const int64_t lane_off = (tile * D + 4 * g) * kTC + col;         // row 4g of a D-row tile
-    const int64_t lane_off_h = (tile * (D / 2) + 4 * g) * kTC + col;  // ... of a D/2-row tile
+    uint32_t* wsu = reinterpret_cast<uint32_t*>(a.ws);
+    const int64_t lane_off = (tile * D + 2 * g) * kTC + col;         // pair-row 2g, high-part plane, of a D-row tile
+    const int64_t lane_off_h = (tile * (D / 2) + 2 * g) * kTC + col;  // ... of a D/2-row tile
+    constexpr int64_t planeD = (D / 2) * kTC, planeH = (D / 4) * kTC;
     Frag A[NT], B[NT];
     const uint32_t* mk = reinterpret_cast<const uint32_t*>(a.ws + a.off_mask) + ((tile * 4 + g) * kTC + col) * 2;
     {  // branch output: d Bo = W_rgb^T dz, masked by Bo > 0 (models.py:133-134), VALU
       const uint32_t bbits = mk[L * a.mask_stride];
-      float* dbo = a.ws + a.off_dbo + lane_off_h;
+      uint32_t* dbo = wsu + a.off_dbo + lane_off_h;
       const float* wr = net.aux + (L + 3) * D + 4 * g;
 #pragma unroll
       for (int ks = 0; ks < NT / 2; ++ks) {
@@ -359,25 +387,24 @@ __global__ __launch_bounds__(kThreads) void k_train_bwd(TrainBwdArgs a) {
           const f32x4 w2 = *reinterpret_cast<const f32x4*>(wr + 2 * (D / 2) + 32 * ks + 16 * hh);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const int off = (32 * ks + 16 * hh + j) * kTC;
             const float val = (dz[0] * w0[j] + dz[1] * w1[j]) + dz[2] * w2[j];
-            const float r = ((bbits >> (8 * ks + 4 * hh + j)) & 1u) ? val : 0.f;
-            dbo[off] = r;
-            v[4 * hh + j] = r;
+            v[4 * hh + j] = ((bbits >> (8 * ks + 4 * hh + j)) & 1u) ? val : 0.f;
           }
         }
         split_store<F16, X3>(v, B[ks]);
+        store_pair_parts<X3>(dbo, planeH, ks, B[ks]);
       }
     }
     {  // d feat = W_branch[:, :D]^T dBo  -> "dPre" of the connection (no activation, models.py:130)
-      BwdStoreHook hk{a.ws + a.off_dp + L * a.h_stride + lane_off};
+      BwdStoreHook hk{wsu + a.off_dp + L * a.h_stride + lane_off, planeD};
       gemm_layer<PREC, NT, NT / 2, 0, EPI_CVT>(st, net, 0, B, none, A, heads, ring, g, hk);
     }
     {  // d h_{L-1} = W_conn^T d feat + d sigma w_sigma, masked by h_{L-1} > 0
       BwdMaskHook<true> hk;
       hk.b0 = mk[(L - 1) * a.mask_stride];
       hk.b1 = mk[(L - 1) * a.mask_stride + 1];
-      hk.d = a.ws + a.off_dp + (L - 1) * a.h_stride + lane_off;
+      hk.d = wsu + a.off_dp + (L - 1) * a.h_stride + lane_off;
+      hk.plane = planeD;
       hk.dsig = dsig;
       hk.wsig = net.aux + (L + 2) * D + 4 * g;
       gemm_layer<PREC, NT, NT, 0, EPI_CVT>(st, net, 0, A, none, B, heads, ring, g, hk);
@@ -388,14 +415,16 @@ __global__ __launch_bounds__(kThreads) void k_train_bwd(TrainBwdArgs a) {
         BwdMaskHook<false> hk;
         hk.b0 = mk[(l - 1) * a.mask_stride];
         hk.b1 = mk[(l - 1) * a.mask_stride + 1];
-        hk.d = a.ws + a.off_dp + (l - 1) * a.h_stride + lane_off;
+        hk.d = wsu + a.off_dp + (l - 1) * a.h_stride + lane_off;
+        hk.plane = planeD;
         gemm_layer<PREC, NT, NT, 0, EPI_CVT>(st, net, 0, B, none, A, heads, ring, g, hk);
       }
       if (l - 1 >= 1) {
         BwdMaskHook<false> hk;
         hk.b0 = mk[(l - 2) * a.mask_stride];
         hk.b1 = mk[(l - 2) * a.mask_stride + 1];
-        hk.d = a.ws + a.off_dp + (l - 2) * a.h_stride + lane_off;
+        hk.d = wsu + a.off_dp + (l - 2) * a.h_stride + lane_off;
+        hk.plane = planeD;
         gemm_layer<PREC, NT, NT, 0, EPI_CVT>(st, net, 0, A, none, B, heads, ring, g, hk);
       }
     }
@@ -406,10 +435,10 @@ __global__ __launch_bounds__(kThreads) void k_train_bwd(TrainBwdArgs a) {
 
 // ------------------------------------------------------------------ wgrad
 struct WgJob {
-  const float* A;  // dPre, T-layout with a_rows rows
-  const float* B;  // layer input, T-layout with b_rows rows
-  float* part;     // [nsplit][a_rows][b_rows]
-  float* bpart;    // [nsplit][a_rows] row sums of A (bias gradient)
+  const uint32_t* A;  // dPre, packed T-layout with a_rows rows
+  const uint32_t* B;  // layer input, packed T-layout with b_rows rows
+  float* part;        // [nsplit][a_rows][b_rows]
+  float* bpart;       // [nsplit][a_rows] row sums of A (bias gradient)
   int32_t b_rows;
 };
 constexpr int kMaxJobs = kMaxLayers + 2;
@@ -419,10 +448,6 @@ struct WgArgs {
   int32_t nsplit;
 };
 
-// wgrad operand loads stay ordinary loads: the two column-group waves that share an A row block find the second
-// read in L2 (nontemporal loads cost 35 % here), while the savers' streaming STORES gain 15 %.
-#define FSN_STREAM_LOAD(p) (*reinterpret_cast<const f32x4*>(p))
-
 template <bool F16>
 __device__ __forceinline__ f32x16 mfma32(const s16x8& a, const s16x8& b, const f32x16& c) {
   if (F16)
@@ -430,25 +455,57 @@ __device__ __forceinline__ f32x16 mfma32(const s16x8& a, const s16x8& b, const f
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// the two rows of a pair-row out of 8 packed dwords (8 samples): low halves -> row 2q, high halves -> row 2q+1
+__device__ __forceinline__ void unzip_rows(const u32x4& d0, const u32x4& d1, s16x8& even, s16x8& odd) {
+  u32x4 e, o;
+  e[0] = __builtin_amdgcn_perm(d0[1], d0[0], 0x05040100u); o[0] = __builtin_amdgcn_perm(d0[1], d0[0], 0x07060302u);
+  e[1] = __builtin_amdgcn_perm(d0[3], d0[2], 0x05040100u); o[1] = __builtin_amdgcn_perm(d0[3], d0[2], 0x07060302u);
+  e[2] = __builtin_amdgcn_perm(d1[1], d1[0], 0x05040100u); o[2] = __builtin_amdgcn_perm(d1[1], d1[0], 0x07060302u);
+  e[3] = __builtin_amdgcn_perm(d1[3], d1[2], 0x05040100u); o[3] = __builtin_amdgcn_perm(d1[3], d1[2], 0x07060302u);
+  even = __builtin_bit_cast(s16x8, e);
+  odd = __builtin_bit_cast(s16x8, o);
+}
+
+// sum of the 8 16-bit elements of a fragment, accumulated in fp32 (v_dot2c with ones)
+template <bool F16>
+__device__ __forceinline__ float dot2_ones(uint32_t w, float acc) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+  if (F16) return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, w), h2{(_Float16)1.0f, (_Float16)1.0f}, acc, false);
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, w), b2{(__bf16)1.0f, (__bf16)1.0f}, acc, false);
+}
+template <bool F16>
+__device__ __forceinline__ float frag_sum(const s16x8& f, float acc) {
+  const u32x4 w = __builtin_bit_cast(u32x4, f);
+  acc = dot2_ones<F16>(w.x, acc);
+  acc = dot2_ones<F16>(w.y, acc);
+  acc = dot2_ones<F16>(w.z, acc);
+  acc = dot2_ones<F16>(w.w, acc);
+  return acc;
+}
+
 // Workgroup = 8 waves as MG row groups (64 rows of A each: two 32-row MFMA tiles) x CG = 8/MG column groups
-// (BT 32-row tiles of B each).  Per 32-sample chunk: the B rows are converted to 16-bit high/low parts and
-// staged in LDS in MFMA-operand order (double buffered, register prefetch of the next chunk); each wave loads
-// its own A rows straight from HBM/L2 (32 contiguous bytes per lane and k-step), converts them in registers
-// and accumulates their row sums for the bias gradient.
+// (BT 32-row tiles of B each).  Per 32-sample chunk: each wave loads its own A pair-rows straight from HBM/L2 (32
+// contiguous bytes per lane, k-step and plane) - MFMA tile 0 takes the EVEN rows of the wave's 64-row block, tile 1
+// the ODD rows, so that both halves of every loaded dword are this lane's operands; the B pair-rows are unzipped
+// into MFMA-operand order in LDS (double buffered, register prefetch of the next chunk).  No fp32 -> 16-bit
+// conversion happens here: the savers stored the parts.  Bias gradient = row sums of A (v_dot2c on the fragments).
 template <int MG, int BT, int PREC>
 __global__ __launch_bounds__(kThreads) void k_wgrad(WgArgs a) {
   constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
+  constexpr int NPL = X3 ? 2 : 1;  // planes: high parts (, low parts)
   constexpr int CG = 8 / MG;
   constexpr int A_ROWS = 64 * MG;
   constexpr int B_ROWS_MAX = CG * BT * 32;
-  constexpr int NB = (B_ROWS_MAX * 4 + kThreads - 1) / kThreads;  // staged items per thread
+  constexpr int NB = (B_ROWS_MAX * 2 + kThreads - 1) / kThreads;  // staged items (pair-row x 8 samples) per thread
   __shared__ __attribute__((aligned(16))) char lds[2][2][B_ROWS_MAX * 64];  // [buffer][hi/lo][(tile,kstep,lane) x 16 B]
   const WgJob jb = a.job[blockIdx.y];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int rg = wave % MG, cg = wave / MG;
   const int m = lane & 31, kg = lane >> 5;
-  const int b_rows = jb.b_rows;
+  const int b_rows = jb.b_rows, b_pairs = b_rows >> 1;
   const bool active = cg * BT * 32 < b_rows;
+  const bool want_bias = jb.bpart && cg == 0;
   const int64_t t0 = (int64_t)blockIdx.x * a.T / a.nsplit, t1 = (int64_t)(blockIdx.x + 1) * a.T / a.nsplit;
   const int64_t nchunk = (t1 - t0) * 4;
 
@@ -461,46 +518,50 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgArgs a) {
       for (int r = 0; r < 16; ++r) acc[ti][bt][r] = 0.f;
   float bsum[2] = {0.f, 0.f};
 
-  // staging item q = it*512 + tid: row R = 16 (q>>6) + (q&15), sample group sg = (q>>4)&3
+  // staging item q = it*512 + tid: pair-row PR = 16 (q>>6) + (q&15), sample group sg = (q>>4)&3
   const int sg = (tid >> 4) & 3;
-  f32x4 braw[NB][2];
-  f32x4 araw[2][2][2];  // [tile][k-step][half]
+  u32x4 braw[NB][NPL][2];
+  u32x4 araw[2][NPL][2];  // [k-step][plane][half]
   auto load_chunk = [&](int64_t ci) {
     const int64_t t = t0 + (ci >> 2);
     const int c = (int)(ci & 3);
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
-      const int R = 16 * ((it * kThreads + tid) >> 6) + (tid & 15);
-      if (R < b_rows) {
-        const float* p = jb.B + (t * b_rows + R) * kTC + 32 * c + 8 * sg;
-        braw[it][0] = FSN_STREAM_LOAD(p);
-        braw[it][1] = FSN_STREAM_LOAD(p + 4);
+      const int PR = 16 * ((it * kThreads + tid) >> 6) + (tid & 15);
+      if (PR < b_pairs) {
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+          const uint32_t* p = jb.B + ((t * 2 + pl) * b_pairs + PR) * kTC + 32 * c + 8 * sg;
+          braw[it][pl][0] = *reinterpret_cast<const u32x4*>(p);
+          braw[it][pl][1] = *reinterpret_cast<const u32x4*>(p + 4);
+        }
       }
     }
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int pl = 0; pl < NPL; ++pl) {
         // k order inside the 32-sample chunk: lane group kg takes samples [16 kg, 16 kg + 16) (8 per k-step), so its
-        // four loads of a row are 64 contiguous bytes; the B staging below uses the same order
-        const float* p = jb.A + (t * A_ROWS + 64 * rg + 32 * ti + m) * kTC + 32 * c + 16 * kg + 8 * ks;
-        araw[ti][ks][0] = FSN_STREAM_LOAD(p);
-        araw[ti][ks][1] = FSN_STREAM_LOAD(p + 4);
+        // loads of a pair-row are 64 contiguous bytes per plane; the B staging below uses the same order
+        const uint32_t* p = jb.A + ((t * 2 + pl) * (A_ROWS / 2) + 32 * rg + m) * kTC + 32 * c + 16 * kg + 8 * ks;
+        araw[ks][pl][0] = *reinterpret_cast<const u32x4*>(p);
+        araw[ks][pl][1] = *reinterpret_cast<const u32x4*>(p + 4);
       }
   };
   auto stage_b = [&](int buf) {
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
-      const int R = 16 * ((it * kThreads + tid) >> 6) + (tid & 15);
-      if (R < b_rows) {
-        float v[8];
+      const int PR = 16 * ((it * kThreads + tid) >> 6) + (tid & 15);
+      if (PR < b_pairs) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { v[j] = braw[it][0][j]; v[4 + j] = braw[it][1][j]; }
-        Frag f;
-        FSN_WG_SPLIT<F16, X3>(v, f);
-        const int addr = ((((R >> 5) * 2 + (sg & 1)) * 64) + (sg >> 1) * 32 + (R & 31)) * 16;  // sg = 2 kg + ks
-        *reinterpret_cast<s16x8*>(&lds[buf][0][addr]) = f.hi;
-        if (X3) *reinterpret_cast<s16x8*>(&lds[buf][1][addr]) = f.lo;
+        for (int pl = 0; pl < NPL; ++pl) {
+          s16x8 ev, od;
+          unzip_rows(braw[it][pl][0], braw[it][pl][1], ev, od);
+          const int R = 2 * PR;  // rows R (even) and R + 1 (odd) sit next to each other in a tile's operand image
+          const int addr = ((((R >> 5) * 2 + (sg & 1)) * 64) + (sg >> 1) * 32 + (R & 31)) * 16;  // sg = 2 kg + ks
+          *reinterpret_cast<s16x8*>(&lds[buf][pl][addr]) = ev;
+          *reinterpret_cast<s16x8*>(&lds[buf][pl][addr + 16]) = od;
+        }
       }
     }
   };
@@ -512,19 +573,22 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgArgs a) {
   __syncthreads();
   for (int64_t ci = 0; ci < nchunk; ++ci) {
     const int buf = (int)(ci & 1);
-    // this chunk's A operands: fp32 -> 16-bit parts (and the bias row sums)
+    // this chunk's A operands: tile 0 = even rows, tile 1 = odd rows of the block (and the bias row sums)
     Frag af[2][2];
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+    for (int ks = 0; ks < 2; ++ks) {
+      unzip_rows(araw[ks][0][0], araw[ks][0][1], af[0][ks].hi, af[1][ks].hi);
+      if (X3) unzip_rows(araw[ks][1][0], araw[ks][1][1], af[0][ks].lo, af[1][ks].lo);
+    }
+    if (want_bias) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        float v[8];
+      for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { v[j] = araw[ti][ks][0][j]; v[4 + j] = araw[ti][ks][1][j]; }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) bsum[ti] += v[j];
-        FSN_WG_SPLIT<F16, X3>(v, af[ti][ks]);
-      }
+        for (int ks = 0; ks < 2; ++ks) {
+          bsum[ti] = frag_sum<F16>(af[ti][ks].hi, bsum[ti]);
+          if (X3) bsum[ti] = frag_sum<F16>(af[ti][ks].lo, bsum[ti]);
+        }
+    }
     if (ci + 1 < nchunk) load_chunk(ci + 1);  // next chunk's global loads fly under the MFMAs
     if (active) {
 #pragma unroll
@@ -548,7 +612,8 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgArgs a) {
     if (ci + 1 < nchunk) stage_b(buf ^ 1);
     __syncthreads();
   }
-  // partial block: C layout of the 32x32 tile: column = lane&31, row = (r&3) + 8 (r>>2) + 4 (lane>>5)
+  // partial block: C layout of the 32x32 tile: column = lane&31, tile row = (r&3) + 8 (r>>2) + 4 (lane>>5); tile ti's
+  // row q is row 2 q + ti of the wave's 64-row block
   if (active) {
     float* part = jb.part + (int64_t)blockIdx.x * A_ROWS * b_rows;
 #pragma unroll
@@ -557,16 +622,16 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgArgs a) {
       for (int bt = 0; bt < BT; ++bt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = 64 * rg + 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * kg;
+          const int row = 64 * rg + 2 * ((r & 3) + 8 * (r >> 2) + 4 * kg) + ti;
           const int cc = (cg * BT + bt) * 32 + m;
           part[(int64_t)row * b_rows + cc] = acc[ti][bt][r];
         }
   }
-  if (jb.bpart && cg == 0) {
+  if (want_bias) {
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti) {
       const float v = bsum[ti] + __shfl_xor(bsum[ti], 32, 64);
-      if (kg == 0) jb.bpart[(int64_t)blockIdx.x * A_ROWS + 64 * rg + 32 * ti + m] = v;
+      if (kg == 0) jb.bpart[(int64_t)blockIdx.x * A_ROWS + 64 * rg + 2 * m + ti] = v;
     }
   }
 }
@@ -620,17 +685,21 @@ __global__ void k_wgrad_reduce(RdArgs a) {
 
 // ------------------------------------------------------------------ head weights
 // dW_sigma[f] = sum_s dsigma_s h_{L-1}[f,s];  dW_rgb[c,f] = sum_s dz_c,s Bo[f,s];  biases = sums of dsigma / dz.
-// Wave w owns 4 NT rows of h_{L-1} and 2 NT rows of Bo; lanes run along the samples (512-byte coalesced rows).
+// Wave w owns 2 NT pair-rows of h_{L-1} and NT pair-rows of Bo (packed T-layout: value = high part + low part);
+// lanes run along the samples (512-byte coalesced rows per plane).
 struct HeadsArgs {
-  const float *H, *Bo, *dhead;
+  const uint32_t *H, *Bo;
+  const float* dhead;
   float* hpart;  // [nsplit][D + 3 D/2 + 4]
   int64_t T;
   int32_t nsplit;
 };
 
-template <int NT>
+template <int NT, int PREC>
 __global__ __launch_bounds__(kThreads) void k_heads_wgrad(HeadsArgs a) {
+  constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
   constexpr int D = 32 * NT, RS = 4 * NT, RR = 2 * NT;
+  typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t t0 = (int64_t)blockIdx.x * a.T / a.nsplit, t1 = (int64_t)(blockIdx.x + 1) * a.T / a.nsplit;
   float accS[RS], accR[3][RR], accB[4] = {0.f, 0.f, 0.f, 0.f};
@@ -640,24 +709,45 @@ __global__ __launch_bounds__(kThreads) void k_heads_wgrad(HeadsArgs a) {
   for (int c = 0; c < 3; ++c)
 #pragma unroll
     for (int r = 0; r < RR; ++r) accR[c][r] = 0.f;
+  // the two rows of pair-row q at samples 2 lane, 2 lane + 1: v[row parity][sample]
+  auto load_pair = [&](const uint32_t* p, int64_t plane, float (&v)[2][2]) {
+    const u32x2 h = *reinterpret_cast<const u32x2*>(p);
+    u32x2 l = {0u, 0u};
+    if (X3) l = *reinterpret_cast<const u32x2*>(p + plane);
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      v[0][sidx] = from_h<F16>((short)(h[sidx] & 0xffffu));
+      v[1][sidx] = from_h<F16>((short)(h[sidx] >> 16));
+      if (X3) {
+        v[0][sidx] += from_h<F16>((short)(l[sidx] & 0xffffu));
+        v[1][sidx] += from_h<F16>((short)(l[sidx] >> 16));
+      }
+    }
+  };
   for (int64_t t = t0; t < t1; ++t) {
     f32x2 dh[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) dh[c] = *reinterpret_cast<const f32x2*>(a.dhead + (t * 4 + c) * kTC + 2 * lane);
 #pragma unroll
     for (int c = 0; c < 4; ++c) accB[c] += dh[c][0] + dh[c][1];
-    const float* hp = a.H + (t * D + RS * wave) * kTC + 2 * lane;
+    const uint32_t* hp = a.H + (t * D + (RS / 2) * wave) * kTC + 2 * lane;
 #pragma unroll
-    for (int r = 0; r < RS; ++r) {
-      const f32x2 h = *reinterpret_cast<const f32x2*>(hp + r * kTC);
-      accS[r] += dh[3][0] * h[0] + dh[3][1] * h[1];
+    for (int q = 0; q < RS / 2; ++q) {
+      float h[2][2];
+      load_pair(hp + q * kTC, (D / 2) * kTC, h);
+      accS[2 * q] += dh[3][0] * h[0][0] + dh[3][1] * h[0][1];
+      accS[2 * q + 1] += dh[3][0] * h[1][0] + dh[3][1] * h[1][1];
     }
-    const float* bp = a.Bo + (t * (D / 2) + RR * wave) * kTC + 2 * lane;
+    const uint32_t* bp = a.Bo + (t * (D / 2) + (RR / 2) * wave) * kTC + 2 * lane;
 #pragma unroll
-    for (int r = 0; r < RR; ++r) {
-      const f32x2 b = *reinterpret_cast<const f32x2*>(bp + r * kTC);
+    for (int q = 0; q < RR / 2; ++q) {
+      float b[2][2];
+      load_pair(bp + q * kTC, (D / 4) * kTC, b);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) accR[c][r] += dh[c][0] * b[0] + dh[c][1] * b[1];
+      for (int c = 0; c < 3; ++c) {
+        accR[c][2 * q] += dh[c][0] * b[0][0] + dh[c][1] * b[0][1];
+        accR[c][2 * q + 1] += dh[c][0] * b[1][0] + dh[c][1] * b[1][1];
+      }
     }
   }
   float* out = a.hpart + (int64_t)blockIdx.x * (D + 3 * (D / 2) + 4);
@@ -838,13 +928,14 @@ int fused_train_bwd(const fsn_mlp_desc* d, int prec, const float* const* W, int6
   RdArgs rd{};
   int nrd = 0;
   float* part = ws + F.part;
+  auto U = [](const float* q) { return reinterpret_cast<const uint32_t*>(q); };  // saved tensors: packed T-layout
   auto H = [&](int i) { return ws + F.h + i * F.h_stride; };
   auto dP = [&](int i) { return ws + F.dp + i * F.h_stride; };
   auto add = [&](int kind, const float* A, const float* B, int a_rows, int b_rows, bool bias, float* dWp, float* dbp, int ld,
                  int col0, int mode, int n_freqs) {
     const int64_t ns = F.nsplit[kind];
     WgJob& j = wa[kind].job[cnt[kind]++];
-    j.A = A; j.B = B; j.b_rows = b_rows;
+    j.A = U(A); j.B = U(B); j.b_rows = b_rows;
     j.part = part; part += ns * a_rows * b_rows;
     j.bpart = nullptr;
     if (bias) { j.bpart = part; part += ns * a_rows; }
@@ -885,9 +976,18 @@ int fused_train_bwd(const fsn_mlp_desc* d, int prec, const float* const* W, int6
   }
   // ---- heads
   {
-    HeadsArgs ha{H(L - 1), ws + F.bo, ws + F.dhead, ws + F.hpart, F.T, F.nsplit_heads};
-    if (D == 256) k_heads_wgrad<8><<<(unsigned)F.nsplit_heads, kThreads, 0, s>>>(ha);
-    else k_heads_wgrad<4><<<(unsigned)F.nsplit_heads, kThreads, 0, s>>>(ha);
+    HeadsArgs ha{U(H(L - 1)), U(ws + F.bo), ws + F.dhead, ws + F.hpart, F.T, F.nsplit_heads};
+    const unsigned hg = (unsigned)F.nsplit_heads;
+    switch ((D == 256 ? 4 : 0) + prec) {
+      case 0: k_heads_wgrad<4, 0><<<hg, kThreads, 0, s>>>(ha); break;
+      case 1: k_heads_wgrad<4, 1><<<hg, kThreads, 0, s>>>(ha); break;
+      case 2: k_heads_wgrad<4, 2><<<hg, kThreads, 0, s>>>(ha); break;
+      case 3: k_heads_wgrad<4, 3><<<hg, kThreads, 0, s>>>(ha); break;
+      case 4: k_heads_wgrad<8, 0><<<hg, kThreads, 0, s>>>(ha); break;
+      case 5: k_heads_wgrad<8, 1><<<hg, kThreads, 0, s>>>(ha); break;
+      case 6: k_heads_wgrad<8, 2><<<hg, kThreads, 0, s>>>(ha); break;
+      default: k_heads_wgrad<8, 3><<<hg, kThreads, 0, s>>>(ha); break;
+    }
     FSN_LAUNCH_CHECK("k_heads_wgrad");
     HeadsRdArgs hr{ws + F.hpart, F.nsplit_heads, D, grad_scale_dev, dW[L], db[L], dW[L + 3], db[L + 3], status};
     const int nn = D + 3 * (D / 2) + 4;
