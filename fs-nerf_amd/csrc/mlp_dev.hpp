@@ -676,11 +676,13 @@ struct AccSets {
       [b8h] "v"(FSN_B(8).hi), [b8l] "v"(FSN_B(8).lo), [b9h] "v"(FSN_B(9).hi), [b9l] "v"(FSN_B(9).lo),            \
       [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [abn] "v"(abn), [voff] "v"(voff),          \
       [mv0] "s"(mv[0]), [gb0] "s"(gb[0]), [mv1] "s"(mv[1]), [gb1] "s"(gb[1]), [mv2] "s"(mv[2]), [gb2] "s"(gb[2])
-// one asm statement: text variant TXT (both MFMA element types), output list OUTS
+// one asm statement: text variant TXT (both MFMA element types), output list OUTS.  "scc": the phase openings compare
+// (s_cmp_ge_u32); without the clobber hipcc may carry a condition of its own across the block (found when the standalone
+// MLP kernel was built on these blocks: its stream pointers were then selected by the block's comparison)
 #define FSN_KLOOP_EMIT(TXT, OUTS)                                                                       \
   do {                                                                                                  \
-    if constexpr (F16) asm volatile(TXT("v_mfma_f32_16x16x32_f16") : OUTS : FSN_KLOOP_INS : "memory");  \
-    else asm volatile(TXT("v_mfma_f32_16x16x32_bf16") : OUTS : FSN_KLOOP_INS : "memory");               \
+    if constexpr (F16) asm volatile(TXT("v_mfma_f32_16x16x32_f16") : OUTS : FSN_KLOOP_INS : "memory", "scc");  \
+    else asm volatile(TXT("v_mfma_f32_16x16x32_bf16") : OUTS : FSN_KLOOP_INS : "memory", "scc");               \
   } while (0)
 #define FSN_KLOOP_CASE(MODE, NU_, OFF_)                                                                         \
   if constexpr (NU == NU_ && OFF == OFF_) {                                                                     \
