@@ -49,6 +49,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ABL = os.environ.get("FSN_KLOOP_ABL", "")
 WAIT2 = os.environ.get("FSN_KLOOP_WAIT2", "1") == "1"
 ILV = os.environ.get("FSN_KLOOP_ILV", "0") == "1"
+SPREAD = os.environ.get("FSN_KLOOP_SPREAD", "0") == "1"
 UPP = 8        # units per 16-KiB phase (a unit = 1 KiB high + 1 KiB low parts)
 UB = 2048      # bytes per unit in the x3 stream layout
 D = int(os.environ.get("FSN_KLOOP_D", "2"))   # units of A operands in flight ahead of the MFMAs (D + 1 register sets)
@@ -90,7 +91,8 @@ def block(mode, nu, off, kind, par):
     fill = [(t, False) for t in epilogue(kind, other)]
     # next pair's bias into the other set, after the epilogue has consumed it
     fill += [(f"ds_read_b128 {tile(other, 0)}, %[abn]", True), (f"ds_read_b128 {tile(other, 1)}, %[abn] offset:64", True)]
-    state = {"n_mfma": 0, "n_lds": 0}
+    state = {"n_mfma": 0, "n_lds": 0, "dma_every": 3, "dma_wait": 0}
+    pend = []   # (FSN_KLOOP_SPREAD) instruction groups of the current stage still to be issued
     # fillers per unit (three MFMAs): issue-slot budget of a SIMD shared by its two waves is ~24 slots per unit
     # pair, of which the MFMAs, A reads and waits of both waves take 18 (measured: three fillers per unit cost
     # ~20 cycles each); FSN_KLOOP_FILL overrides for experiments
@@ -123,6 +125,12 @@ def block(mode, nu, off, kind, par):
         c = tile(cur, t)
         emit(f"MFMA {c}, %[s{s}], %[b{bop}], {c}")
         state["n_mfma"] += 1
+        if pend:
+            state["dma_wait"] -= 1
+            if state["dma_wait"] <= 0:
+                for t in pend.pop(0):
+                    ins.append(t)
+                state["dma_wait"] = state["dma_every"]
         if state["n_mfma"] >= 3:
             for _ in range(n_fill):
                 if fill:
@@ -139,7 +147,22 @@ def block(mode, nu, off, kind, par):
             # (FSN_KLOOP_ABL: timing experiments that drop parts of this - results are then garbage)
             if "nobarrier" not in ABL:
                 ins += [f"s_waitcnt vmcnt({LOADS})", "s_barrier"]
-            if "nodma" not in ABL:
+            if "nodma" not in ABL and SPREAD:
+                # FSN_KLOOP_SPREAD: the four loads of a loader wave are issued one at a time behind the following
+                # MFMAs instead of back to back behind the barrier (tools/ubench/gen_issue.py: a burst of four costs
+                # a w8 stream 11 points of matrix-pipe time, spread loads 3).  SCC holds "not a loader wave" and M0
+                # the stage's LDS base until the last of them (nothing else in a block writes either).
+                ins += ["v_readfirstlane_b32 %[keep], %[voff]", f"s_cmp_ge_u32 %[keep], {LOADS * 1024 * 4}",
+                        "s_mov_b32 %[keep], m0", f"s_mov_b32 m0, %[mv{ev}]"]
+                left = (nu - u) * (3 if mode == "X3" else 2)   # MFMAs from here to the end of the block
+                state["dma_every"] = max(1, min(3 if mode == "X3" else 2, left // (LOADS + 1)))
+                state["dma_wait"] = state["dma_every"]
+                for i in range(LOADS):
+                    pend.append([f"s_cbranch_scc1 .Lnl{ev}_{i}_%=",
+                                 f"global_load_lds_dwordx4 %[voff], %[gb{ev}]" + (f" offset:{1024 * i}" if i else ""),
+                                 f".Lnl{ev}_{i}_%=:"])
+                pend.append(["s_mov_b32 m0, %[keep]"])
+            elif "nodma" not in ABL:
                 # only the loader waves (0..3, %[ldr] != 0) issue LDS-DMA: the stall of issuing them then falls
                 # beside the MFMAs of their SIMD partners (waves 4..7) instead of on both waves at once
                 # (the predicate is taken from voff = 4096*wave + 16*lane: an "s" input operand may silently arrive in
@@ -191,6 +214,9 @@ def block(mode, nu, off, kind, par):
         if mode == "X3":
             mfma(t, f"{s}l", f"{k}h", share[1])
         mfma(t, f"{s}h", f"{k}l", share[-1])
+    for grp in pend:            # (a stage opened close to the end of the block)
+        ins.extend(grp)
+    pend.clear()
     for text, is_lds in fill:   # (short pairs: what did not fit beside the MFMAs)
         emit(text, is_lds)
     ins += ["s_waitcnt lgkmcnt(0)", "s_nop 7", "s_nop 3"]
