@@ -85,3 +85,17 @@ def test_host_layer_has_no_cpu_fallback():
         NeRF(3, 3, 8, 256, (7,), pos_fn={"n_freqs": 10, "log_space": True},
              dir_fn={"n_freqs": 4, "log_space": True}).eval().packed()
     assert U.get_chunks(torch.zeros(10, 3), 4)[-1].shape == (2, 3)
+
+
+def test_generated_asm_blocks_declare_the_scc_clobber():
+    """The k-loop blocks (csrc/kloop_gen.hpp) compare in their phase openings; the asm statements that carry them must
+    tell the compiler so (tools/scan_asm_scc.py checks the compiled code for the consequence)."""
+    import os
+    import re
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fs-nerf_amd", "csrc")
+    gen = open(os.path.join(csrc, "kloop_gen.hpp")).read()
+    assert "s_cmp_ge_u32" in gen
+    dev = open(os.path.join(csrc, "mlp_dev.hpp")).read()
+    emit = dev[dev.index("#define FSN_KLOOP_EMIT"):dev.index("#define FSN_KLOOP_CASE")]
+    stmts = re.findall(r"asm volatile\(TXT\([^;]*;", emit)
+    assert len(stmts) == 2 and all('"scc"' in st and '"memory"' in st for st in stmts), stmts
