@@ -93,7 +93,8 @@ def main():
         optimizer.zero_grad()
         estimator.update_every_n_steps(step=k, occ_eval_fn=occ_eval_fn, occ_thre=1e-2)
         if k % 100 == 0 or k == a.iters - 1:
-            print(f"iter {k:5d}  loss {float(loss):.5f}  psnr {-10 * math.log10(max(float(loss), 1e-10)):.2f} dB", flush=True)
+            lv = float(loss.detach())
+            print(f"iter {k:5d}  loss {lv:.5f}  psnr {-10 * math.log10(max(lv, 1e-10)):.2f} dB", flush=True)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     model.eval()
