@@ -522,7 +522,10 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgArgs a) {
   const int sg = (tid >> 4) & 3;
   u32x4 braw[NB][NPL][2];
   u32x4 araw[2][NPL][2];  // [k-step][plane][half]
-  auto load_chunk = [&](int64_t ci) {
+  // B raw of chunk ci+2 is requested as soon as the staging of chunk ci+1 has consumed the registers (bottom of
+  // iteration ci), A raw of chunk ci+1 as soon as chunk ci's fragments are unzipped (top): every load has a whole
+  // iteration (MFMA phase + staging) to land, at no register cost.
+  auto load_b = [&](int64_t ci) {
     const int64_t t = t0 + (ci >> 2);
     const int c = (int)(ci & 3);
 #pragma unroll
@@ -537,6 +540,10 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgArgs a) {
         }
       }
     }
+  };
+  auto load_a = [&](int64_t ci) {
+    const int64_t t = t0 + (ci >> 2);
+    const int c = (int)(ci & 3);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -567,8 +574,10 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgArgs a) {
   };
 
   if (nchunk > 0) {
-    load_chunk(0);
+    load_a(0);
+    load_b(0);
     stage_b(0);
+    if (nchunk > 1) load_b(1);
   }
   __syncthreads();
   for (int64_t ci = 0; ci < nchunk; ++ci) {
@@ -589,7 +598,7 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgArgs a) {
           if (X3) bsum[ti] = frag_sum<F16>(af[ti][ks].lo, bsum[ti]);
         }
     }
-    if (ci + 1 < nchunk) load_chunk(ci + 1);  // next chunk's global loads fly under the MFMAs
+    if (ci + 1 < nchunk) load_a(ci + 1);  // next chunk's A loads fly under the MFMAs and the staging
     if (active) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -610,6 +619,7 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgArgs a) {
         }
     }
     if (ci + 1 < nchunk) stage_b(buf ^ 1);
+    if (ci + 2 < nchunk) load_b(ci + 2);
     __syncthreads();
   }
   // partial block: C layout of the 32x32 tile: column = lane&31, tile row = (r&3) + 8 (r>>2) + 4 (lane>>5); tile ti's
