@@ -275,16 +275,18 @@ def dry_run(args, rank, world):
                           "max_over_ranks": float(t.item()), "local_ranks_plus_1": ranks.tolist(), **seen}), flush=True)
 
 
+FUSED_SOURCES = ("render.hip", "mlp_dev.hpp", "kloop_gen.hpp", "ray_dev.hpp", "mlp_layout.hpp", "common.hpp")
+
+
 def csrc_sha():
-    """Hash of the kernel sources the fused launch is built from: a PMC summary is only quoted when it was collected
-    on exactly this code."""
+    """Hash of the sources k_render_fused is built from (render.hip and the headers it includes): a PMC summary is only
+    quoted when it was collected on exactly this code."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "fs-nerf_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in FUSED_SOURCES:
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
