@@ -439,7 +439,7 @@ struct WgJob {
   const uint32_t* B;  // layer input, packed T-layout with b_rows rows
   float* part;        // [nsplit][a_rows][b_rows]
   float* bpart;       // [nsplit][a_rows] row sums of A (bias gradient)
-  int32_t b_rows;
+  int32_t b_rows, a_rows;
 };
 constexpr int kMaxJobs = kMaxLayers + 2;
 struct WgArgs {
@@ -490,20 +490,24 @@ __device__ __forceinline__ float frag_sum(const s16x8& f, float acc) {
 // the ODD rows, so that both halves of every loaded dword are this lane's operands; the B pair-rows are unzipped
 // into MFMA-operand order in LDS (double buffered, register prefetch of the next chunk).  No fp32 -> 16-bit
 // conversion happens here: the savers stored the parts.  Bias gradient = row sums of A (v_dot2c on the fragments).
-template <int MG, int BT, int PREC>
-__global__ __launch_bounds__(kThreads) void k_wgrad(WgArgs a) {
+// NW waves per workgroup (8; 4 = two independent workgroups per CU was tried for the 256x256 jobs, see the launch code);
+// blockIdx.z selects the workgroup's block of A_ROWS = 64 MG rows of A.
+template <int NW, int MG, int BT, int PREC>
+__global__ __launch_bounds__(64 * NW, 2) void k_wgrad(WgArgs a) {  // (2 waves per SIMD: <= 256 registers)
   constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
   constexpr int NPL = X3 ? 2 : 1;  // planes: high parts (, low parts)
-  constexpr int CG = 8 / MG;
+  constexpr int CG = NW / MG;
+  constexpr int NTHR = 64 * NW;
   constexpr int A_ROWS = 64 * MG;
   constexpr int B_ROWS_MAX = CG * BT * 32;
-  constexpr int NB = (B_ROWS_MAX * 2 + kThreads - 1) / kThreads;  // staged items (pair-row x 8 samples) per thread
+  constexpr int NB = (B_ROWS_MAX * 2 + NTHR - 1) / NTHR;  // staged items (pair-row x 8 samples) per thread
   __shared__ __attribute__((aligned(16))) char lds[2][2][B_ROWS_MAX * 64];  // [buffer][hi/lo][(tile,kstep,lane) x 16 B]
   const WgJob jb = a.job[blockIdx.y];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int rg = wave % MG, cg = wave / MG;
   const int m = lane & 31, kg = lane >> 5;
   const int b_rows = jb.b_rows, b_pairs = b_rows >> 1;
+  const int a_tot = jb.a_rows, rb = blockIdx.z;  // this workgroup's rows: [rb A_ROWS, (rb + 1) A_ROWS) of a_tot
   const bool active = cg * BT * 32 < b_rows;
   const bool want_bias = jb.bpart && cg == 0;
   const int64_t t0 = (int64_t)blockIdx.x * a.T / a.nsplit, t1 = (int64_t)(blockIdx.x + 1) * a.T / a.nsplit;
@@ -530,7 +534,7 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgArgs a) {
     const int c = (int)(ci & 3);
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
-      const int PR = 16 * ((it * kThreads + tid) >> 6) + (tid & 15);
+      const int PR = 16 * ((it * NTHR + tid) >> 6) + (tid & 15);
       if (PR < b_pairs) {
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
@@ -550,7 +554,8 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgArgs a) {
       for (int pl = 0; pl < NPL; ++pl) {
         // k order inside the 32-sample chunk: lane group kg takes samples [16 kg, 16 kg + 16) (8 per k-step), so its
         // loads of a pair-row are 64 contiguous bytes per plane; the B staging below uses the same order
-        const uint32_t* p = jb.A + ((t * 2 + pl) * (A_ROWS / 2) + 32 * rg + m) * kTC + 32 * c + 16 * kg + 8 * ks;
+        const uint32_t* p =
+            jb.A + ((t * 2 + pl) * (a_tot / 2) + rb * (A_ROWS / 2) + 32 * rg + m) * kTC + 32 * c + 16 * kg + 8 * ks;
         araw[ks][pl][0] = *reinterpret_cast<const u32x4*>(p);
         araw[ks][pl][1] = *reinterpret_cast<const u32x4*>(p + 4);
       }
@@ -558,7 +563,7 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgArgs a) {
   auto stage_b = [&](int buf) {
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
-      const int PR = 16 * ((it * kThreads + tid) >> 6) + (tid & 15);
+      const int PR = 16 * ((it * NTHR + tid) >> 6) + (tid & 15);
       if (PR < b_pairs) {
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
@@ -625,7 +630,7 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgArgs a) {
   // partial block: C layout of the 32x32 tile: column = lane&31, tile row = (r&3) + 8 (r>>2) + 4 (lane>>5); tile ti's
   // row q is row 2 q + ti of the wave's 64-row block
   if (active) {
-    float* part = jb.part + (int64_t)blockIdx.x * A_ROWS * b_rows;
+    float* part = jb.part + ((int64_t)blockIdx.x * a_tot + rb * A_ROWS) * b_rows;
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -641,7 +646,7 @@ __global__ __launch_bounds__(kThreads) void k_wgrad(WgArgs a) {
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti) {
       const float v = bsum[ti] + __shfl_xor(bsum[ti], 32, 64);
-      if (kg == 0) jb.bpart[(int64_t)blockIdx.x * A_ROWS + 64 * rg + 2 * m + ti] = v;
+      if (kg == 0) jb.bpart[(int64_t)blockIdx.x * a_tot + rb * A_ROWS + 64 * rg + 2 * m + ti] = v;
     }
   }
 }
@@ -841,15 +846,17 @@ static int launch_bwd(const TrainBwdArgs& a, unsigned grid, hipStream_t s) {
   FSN_LAUNCH_CHECK("k_train_bwd");
   return FSN_OK;
 }
-template <int MG, int BT>
+template <int NW, int MG, int BT>
 static int launch_wgrad(int prec, const WgArgs& a, int njobs, hipStream_t s) {
   if (njobs == 0) return FSN_OK;
-  dim3 grid((unsigned)a.nsplit, (unsigned)njobs);
+  const int a_rows = a.job[0].a_rows;  // (jobs of one launch share their shape)
+  FSN_REQUIRE(a_rows % (64 * MG) == 0, FSN_E_HIP, "internal: wgrad row blocks");
+  dim3 grid((unsigned)a.nsplit, (unsigned)njobs, (unsigned)(a_rows / (64 * MG)));
   switch (prec) {
-    case 0: k_wgrad<MG, BT, 0><<<grid, kThreads, 0, s>>>(a); break;
-    case 1: k_wgrad<MG, BT, 1><<<grid, kThreads, 0, s>>>(a); break;
-    case 2: k_wgrad<MG, BT, 2><<<grid, kThreads, 0, s>>>(a); break;
-    default: k_wgrad<MG, BT, 3><<<grid, kThreads, 0, s>>>(a); break;
+    case 0: k_wgrad<NW, MG, BT, 0><<<grid, 64 * NW, 0, s>>>(a); break;
+    case 1: k_wgrad<NW, MG, BT, 1><<<grid, 64 * NW, 0, s>>>(a); break;
+    case 2: k_wgrad<NW, MG, BT, 2><<<grid, 64 * NW, 0, s>>>(a); break;
+    default: k_wgrad<NW, MG, BT, 3><<<grid, 64 * NW, 0, s>>>(a); break;
   }
   FSN_LAUNCH_CHECK("k_wgrad");
   return FSN_OK;
@@ -945,7 +952,7 @@ int fused_train_bwd(const fsn_mlp_desc* d, int prec, const float* const* W, int6
                  int col0, int mode, int n_freqs) {
     const int64_t ns = F.nsplit[kind];
     WgJob& j = wa[kind].job[cnt[kind]++];
-    j.A = U(A); j.B = U(B); j.b_rows = b_rows;
+    j.A = U(A); j.B = U(B); j.b_rows = b_rows; j.a_rows = a_rows;
     j.part = part; part += ns * a_rows * b_rows;
     j.bpart = nullptr;
     if (bias) { j.bpart = part; part += ns * a_rows; }
@@ -967,15 +974,20 @@ int fused_train_bwd(const fsn_mlp_desc* d, int prec, const float* const* W, int6
   const WgArgs &big = wa[WG_BIG], &enc = wa[WG_ENC], &br = wa[WG_BR], &bd = wa[WG_BD];
   const int nbig = cnt[WG_BIG], nenc = cnt[WG_ENC], nbr = cnt[WG_BR], nbd = cnt[WG_BD];
   if (D == 256) {
-    if ((rc = launch_wgrad<4, 4>(prec, big, nbig, s)) != FSN_OK) return rc;
-    if ((rc = launch_wgrad<4, 1>(prec, enc, nenc, s)) != FSN_OK) return rc;
-    if ((rc = launch_wgrad<2, 2>(prec, br, nbr, s)) != FSN_OK) return rc;
-    if ((rc = launch_wgrad<2, 1>(prec, bd, nbd, s)) != FSN_OK) return rc;
+#ifdef FSN_WGRAD_4W  // experiment: two 4-wave workgroups per CU, 128 rows of A each (twice the chunks in flight, but
+    // B is read and staged twice): 3.55 ms against 2.80 ms for the 8-wave form
+    if ((rc = launch_wgrad<4, 2, 4>(prec, big, nbig, s)) != FSN_OK) return rc;
+#else
+    if ((rc = launch_wgrad<8, 4, 4>(prec, big, nbig, s)) != FSN_OK) return rc;
+#endif
+    if ((rc = launch_wgrad<8, 4, 1>(prec, enc, nenc, s)) != FSN_OK) return rc;
+    if ((rc = launch_wgrad<8, 2, 2>(prec, br, nbr, s)) != FSN_OK) return rc;
+    if ((rc = launch_wgrad<8, 2, 1>(prec, bd, nbd, s)) != FSN_OK) return rc;
   } else {
-    if ((rc = launch_wgrad<2, 1>(prec, big, nbig, s)) != FSN_OK) return rc;
-    if ((rc = launch_wgrad<2, 1>(prec, enc, nenc, s)) != FSN_OK) return rc;
-    if ((rc = launch_wgrad<1, 1>(prec, br, nbr, s)) != FSN_OK) return rc;
-    if ((rc = launch_wgrad<1, 1>(prec, bd, nbd, s)) != FSN_OK) return rc;
+    if ((rc = launch_wgrad<8, 2, 1>(prec, big, nbig, s)) != FSN_OK) return rc;
+    if ((rc = launch_wgrad<8, 2, 1>(prec, enc, nenc, s)) != FSN_OK) return rc;
+    if ((rc = launch_wgrad<8, 1, 1>(prec, br, nbr, s)) != FSN_OK) return rc;
+    if ((rc = launch_wgrad<8, 1, 1>(prec, bd, nbd, s)) != FSN_OK) return rc;
   }
   rd.scale = grad_scale_dev;
   rd.status = status;
