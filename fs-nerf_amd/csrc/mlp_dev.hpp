@@ -63,10 +63,13 @@ constexpr int kLead = FSN_LEAD;
 constexpr int kLook = kLead > 0 ? kNSlot - 2 - kLag : kNSlot - 1;
 // loads of this wave that may stay in flight when a phase is opened: the lagging waves' share of a phase must have
 // landed one event before they read it themselves (the leading waves read it then), hence "- kLag"
-// LDS-DMA is issued by the loader waves 0..kLoaders-1 only (one per SIMD): issuing a 1-KiB load costs the wave
+// LDS-DMA is issued by kLoaders loader waves only (one per SIMD; which half of the workgroup: FSN_LOADER_XOR): issuing a 1-KiB load costs the wave
 // 60-185 cycles, and with the workgroup barrier in front of it every wave of the CU used to pay that at the same
 // moment; now the partner wave of each loader (w + 4) runs its MFMAs meanwhile.
 constexpr int kLoaders = 4;
+#ifndef FSN_LOADER_XOR  // 4: the loaders are waves 4..7, the later-dispatched wave of every SIMD (0: waves 0..3;
+#define FSN_LOADER_XOR 4  // measured 396.6 against 399.9 ms per fp16x3 frame, no difference in bf16)
+#endif
 constexpr int kOpenVmcnt = (kLook - 1 - kLag) * (kPhaseBytes / 1024 / kLoaders);
 #ifndef FSN_RING_EXPERIMENT  // (timing experiments with other ring depths: compiler-scheduled paths only)
 static_assert(kOpenVmcnt == 4, "the generated k-loop blocks wait with vmcnt(4)");
@@ -129,10 +132,10 @@ struct WStream {
   // form + immediate offsets need one M0 write and no per-load address VALU.  The immediate
   // offset of global_load_lds advances BOTH the global and the LDS address.
   __device__ __forceinline__ void stage() {
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) ^ FSN_LOADER_XOR);
     // (readfirstlane: the value is wave-uniform, but the "s" constraint needs the compiler to know it)
     const uint32_t m0v = __builtin_amdgcn_readfirstlane(ring_lds + s_slot * kPhaseBytes + wave * (kGldsPerWave * 1024));
-    const uint32_t voff = (threadIdx.x >> 6) * (kGldsPerWave * 1024) + (threadIdx.x & 63) * 16;
+    const uint32_t voff = ((threadIdx.x >> 6) ^ FSN_LOADER_XOR) * (kGldsPerWave * 1024) + (threadIdx.x & 63) * 16;
     const uint64_t sp = (uint64_t)s_ptr;
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sp);
     const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(sp >> 32));
@@ -193,7 +196,7 @@ struct WStream {
   // stager exactly as stage() does.  phase_lds(k): LDS byte address (+ 16*lane) of the k-th phase counted from the
   // one opened last (k = 0).  opened(n): the block executed n openings.
   __device__ __forceinline__ void next_stage(uint32_t& m0v, uint64_t& gbase) {
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) ^ FSN_LOADER_XOR);
     m0v = __builtin_amdgcn_readfirstlane(ring_lds + s_slot * kPhaseBytes + wave * (kGldsPerWave * 1024));
     const uint64_t sp = (uint64_t)s_ptr;
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sp);
@@ -744,7 +747,7 @@ __device__ __forceinline__ void kloop_block(WStream& st, const Frag (&act)[NACT]
   uint64_t gb[3];
   typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
   u32x4 oh, ol;
-  const uint32_t voff = (threadIdx.x >> 6) * (kGldsPerWave * 1024) + (threadIdx.x & 63) * 16;
+  const uint32_t voff = ((threadIdx.x >> 6) ^ FSN_LOADER_XOR) * (kGldsPerWave * 1024) + (threadIdx.x & 63) * 16;
   if constexpr (!TWO) {
     FSN_KLOOP_CASE(X3, 16, 0)
     FSN_KLOOP_CASE(X3, 20, 0)
