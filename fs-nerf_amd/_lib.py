@@ -16,7 +16,8 @@ FSN_PREC_FP16X3 = 2
 FSN_PREC_FP16 = 3
 FSN_PREC_FP32 = 4  # NOT a mode of the product library: the test-only fp32 reference formulation (tests/ref_fp32)
 FSN_PREC_FP16X2 = 6  # two passes (weights high part only), inference only
-FSN_STATUS_FP16_RANGE = 1
+FSN_STATUS_FP16_RANGE = 1  # a value reached fp16 infinity
+FSN_STATUS_FP16_SMALL = 2  # a layer's activations were all below 2^-14: outside the split's float32-grade envelope
 
 
 class MlpDesc(C.Structure):

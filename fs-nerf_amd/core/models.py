@@ -82,8 +82,10 @@ class _NerfTrainFn(torch.autograd.Function):
         model = ctx.model
         if model.range_check and model.fp16_family(ctx.prec):
             model._train_calls += 1
-            if model._train_calls % model.range_check_every == 0 and not ops.range_ok(d_out.device):
-                model.fall_back("training steps (their gradients were zeroed on the device)")
+            if model._train_calls % model.range_check_every == 0:
+                bits = ops.range_flags(d_out.device)
+                if bits:
+                    model.fall_back("training steps (gradients of out-of-range steps were zeroed on the device)", bits)
         db = [g.reshape(-1) for g in db]
         return (None, None, None, *dW, *db)
 
@@ -137,12 +139,14 @@ class NeRF(nn.Module):
     def fp16_family(prec: int) -> bool:
         return prec in (L.FSN_PREC_FP16X3, L.FSN_PREC_FP16, L.FSN_PREC_FP16X2)
 
-    def fall_back(self, what: str) -> None:
-        """An fp16-mode launch reported values outside the fp16 range (|v| >= 65504): continue in the bf16 mode of
-        the same pass structure, which has float32's range.  Never silent."""
+    def fall_back(self, what: str, bits: int = L.FSN_STATUS_FP16_RANGE) -> None:
+        """An fp16-mode launch reported values outside the mode's envelope (|v| >= 65504, or a layer whose activations
+        all sat below 2^-14): continue in the bf16 mode of the same pass structure, which has float32's range.  Never
+        silent."""
         new = self.FALLBACK.get(self.precision, "bf16x3")
-        warnings.warn(f"fs-nerf HIP path: {what}: hidden activations left the fp16 range in precision "
-                      f"'{self.precision}'; re-running / continuing in '{new}'", RuntimeWarning, stacklevel=3)
+        warnings.warn(f"fs-nerf HIP path: {what}: hidden activations left the fp16 range envelope of precision "
+                      f"'{self.precision}' ({ops.describe_flags(bits)}); re-running / continuing in '{new}'",
+                      RuntimeWarning, stacklevel=3)
         self.precision = new
         if self.train_precision in self.FALLBACK:
             self.train_precision = None
@@ -179,7 +183,8 @@ class NeRF(nn.Module):
             return _NerfTrainFn.apply(self, x, dirs, *ws, *bs)
         dev = x.device
         out = ops.mlp_fwd(self.packed(), x, dirs, self._mask(self.pos_mask, dev), self._mask(self.dir_mask, dev))
-        if self.range_check and self.fp16_family(self.PRECISIONS[self.precision]) and not ops.range_ok(dev):
-            self.fall_back("NeRF.forward")
+        bits = ops.range_flags(dev) if self.range_check and self.fp16_family(self.PRECISIONS[self.precision]) else 0
+        if bits:
+            self.fall_back("NeRF.forward", bits)
             out = ops.mlp_fwd(self.packed(), x, dirs, self._mask(self.pos_mask, dev), self._mask(self.dir_mask, dev))
         return out

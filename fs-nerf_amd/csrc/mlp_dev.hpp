@@ -10,9 +10,12 @@
 //  * weights (A operands, pre-packed by mlp_layout.hpp) are streamed L2 -> LDS by
 //    global_load_lds_dwordx4 into a ring of 16-KiB phases shared by the 8 waves, two phases
 //    ahead, with counted vmcnt + raw s_barrier (no full drain inside the stream);
-//  * x3 modes (FSN_PREC_FP16X3 default, FSN_PREC_BF16X3): a.w = ah.wh + al.wh + ah.wl, three MFMA
-//    passes on 16-bit high/low parts with fp32 accumulation (fp16x3 ~ fp32 accuracy, bf16x3
-//    ~1e-5 per product but no range limit); FSN_PREC_BF16 / FSN_PREC_FP16: one pass.
+//  * x3 modes (FSN_PREC_FP16X3 default, FSN_PREC_BF16X3): a.w = ah.wh + (al.wh + ah.wl), three MFMA
+//    passes on 16-bit high/low parts with fp32 accumulation; the two correction products have their
+//    own accumulator, and in the fp16 modes the low parts are kept scaled by 2^11 (mlp_layout.hpp,
+//    kLoScaleF16) so that they are normal fp16 numbers for |v| down to ~6e-5: fp16x3 ~ fp32 accuracy
+//    for layer scales from 2^-14 to 65504 (both ends are detected, never silent); bf16x3
+//    ~1e-5 per product, float32's range; FSN_PREC_BF16 / FSN_PREC_FP16: one pass.
 //  * sigma (256 -> 1) and rgb (128 -> 3) heads are fp32 VALU dot products on the accumulators.
 #pragma once
 #include "common.hpp"
@@ -253,25 +256,25 @@ __device__ __forceinline__ float from_h(short b) {
   if (F16) return (float)__builtin_bit_cast(_Float16, b);
   return (float)__builtin_bit_cast(__bf16, b);
 }
-// plain C++ form of the high / low split (every mode)
+// plain C++ form of the high / low split (every mode); fp16 x3: low part scaled by 2^11 (mlp_layout.hpp)
 template <bool F16, bool X3>
 __device__ __forceinline__ void split_store_cpp(const float v[8], Frag& f) {
+  constexpr float K = (F16 && X3) ? kLoScaleF16 : 1.0f;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const short h = to_h<F16>(v[j]);
     f.hi[j] = h;
-    f.lo[j] = X3 ? to_h<F16>(v[j] - from_h<F16>(h)) : (short)0;
+    f.lo[j] = X3 ? to_h<F16>((v[j] - from_h<F16>(h)) * K) : (short)0;
   }
 }
 
+// The split the epilogues use.  NOTE (fp16 x3, asm form): the inputs must be results of VALU instructions the compiler
+// knows (the epilogue's merge / ReLU), never MFMA accumulators read directly - hipcc pads the XDL-write -> VALU-read
+// wait states only for instructions it sees.
 template <bool F16, bool X3>
 __device__ __forceinline__ void split_store(const float v[8], Frag& f) {
-#ifndef FSN_SPLIT_CPP
+#ifdef FSN_ABL_OLDEPI
   if constexpr (F16 && X3) {
-    // fp16 high / low parts of a pair of values in three instructions: packed round-to-nearest convert, then
-    // low = fp16(v - float(high)) as one mixed-precision fma each (fp32 arithmetic on the fp16 high part, one
-    // rounding to fp16: the same value as the convert-back / subtract / convert sequence, which is exact until the
-    // last step).  Written as asm: hipcc folds fma(h, -1, v) back into a subtraction and then forms v_pk_add_f32.
     typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
     u32x4 h, l;
 #pragma unroll
@@ -290,16 +293,43 @@ __device__ __forceinline__ void split_store(const float v[8], Frag& f) {
     return;
   }
 #endif
+#ifndef FSN_SPLIT_CPP
+  if constexpr (F16 && X3) {
+    // fp16 high part and SCALED low part of a pair of values in five instructions: packed round-to-nearest convert;
+    // r = v - float(high) as one mixed-precision fma each (fp32 result: exact, |r| <= 2^-11 |v|); low = fp16(2^11 r),
+    // again as mixed fma so that the scale costs nothing.  Bit-identical to split_store_cpp (one rounding, in the
+    // last step).  Written as asm: hipcc folds fma(h, -1, v) back into a subtraction and then forms v_pk_add_f32.
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+    u32x4 h, l;
+    const float kk = kLoScaleF16;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const short h = to_h<F16>(v[j]);
-    f.hi[j] = h;
-    f.lo[j] = X3 ? to_h<F16>(v[j] - from_h<F16>(h)) : (short)0;
+    for (int i = 0; i < 4; ++i) {
+      uint32_t hh, ll;
+      float ra, rb;
+      asm("v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+          "v_fma_mix_f32 %2, %0, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
+          "v_fma_mix_f32 %3, %0, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+          "v_fma_mixlo_f16 %1, %2, %6, 0 op_sel_hi:[0,0,0]\n\t"
+          "v_fma_mixhi_f16 %1, %3, %6, 0 op_sel_hi:[0,0,0]"
+          : "=&v"(hh), "=&v"(ll), "=&v"(ra), "=&v"(rb)
+          : "v"(v[2 * i]), "v"(v[2 * i + 1]), "s"(kk));
+      h[i] = hh;
+      l[i] = ll;
+    }
+    f.hi = __builtin_bit_cast(s16x8, h);
+    f.lo = __builtin_bit_cast(s16x8, l);
+    return;
   }
+#endif
+  split_store_cpp<F16, X3>(v, f);
 }
 
-// Range guard of the fp16 modes: running packed maximum of the |high part| bit patterns a wave has produced
-// (0x7c00 = infinity: the value left the fp16 range).  4 instructions per output pair.
+// Range guard of the fp16 modes.  range_track: running packed maximum of the |high part| bit patterns a lane has
+// produced in the current layer (4 instructions per output pair).  range_layer_end: folds it into the tile's overall
+// maximum (0x7c00 = infinity: a value left the fp16 range, FSN_STATUS_FP16_RANGE) and, in the split modes' forward
+// passes (SMALL), looks at the layer's scale: when the largest |high part| of the wave's 16 samples x all features of
+// this layer is non-zero but an fp16 SUBNORMAL (< 2^-14) the split no longer carries 22 bits relative to the layer's
+// scale (high parts on the fixed 2^-24 grid, scaled low parts 2^-36: FSN_STATUS_FP16_SMALL).  Both ends are reported, the host re-runs / continues in bf16x3 (core/models.py).
 template <bool SIGNED>
 __device__ __forceinline__ void range_track(uint32_t& fmax, const s16x8& hi) {
   typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -312,10 +342,34 @@ __device__ __forceinline__ void range_track(uint32_t& fmax, const s16x8& hi) {
   }
 }
 
-// a value reached fp16 infinity somewhere in this wave's tile: tell the host (never silent)
-__device__ __forceinline__ void range_report(uint32_t* status, uint32_t fmax) {
-  const bool bad = (fmax & 0xffffu) >= 0x7c00u || (fmax >> 16) >= 0x7c00u;
-  if (__builtin_amdgcn_readfirstlane((int)__any(bad)) && status) { if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+constexpr uint32_t kSmallBits = 0x0400u;  // fp16 bit pattern of 2^-14, the smallest normal number
+
+struct RangeState {
+  uint32_t fmax;   // this layer, packed pair of u16
+  uint32_t fall;   // all layers of the tile so far
+  uint32_t small;  // wave-uniform: some layer's scale was below kSmallBits
+};
+
+template <bool SMALL>
+__device__ __forceinline__ void range_layer_end(RangeState& r) {
+  asm("v_pk_max_u16 %0, %0, %1" : "+v"(r.fall) : "v"(r.fmax));
+  if constexpr (SMALL) {
+    const uint32_t lo = r.fmax & 0xffffu, hi = r.fmax >> 16;
+    const uint32_t m = lo > hi ? lo : hi;
+    const int any_big = __builtin_amdgcn_readfirstlane((int)__any(m >= kSmallBits));
+    const int any_nz = __builtin_amdgcn_readfirstlane((int)__any(m != 0u));
+    if (!any_big && any_nz) r.small = 1u;
+  }
+  r.fmax = 0u;
+}
+
+// tell the host (never silent): bit 0 = a value reached fp16 infinity, bit 1 = a layer ran below the split's scale
+__device__ __forceinline__ void range_report(uint32_t* status, const RangeState& r) {
+  const uint32_t f = r.fall;
+  const bool bad = (f & 0xffffu) >= 0x7c00u || (f >> 16) >= 0x7c00u;
+  uint32_t bits = __builtin_amdgcn_readfirstlane((int)__any(bad)) ? 1u : 0u;
+  if (__builtin_amdgcn_readfirstlane((int)r.small)) bits |= 2u;
+  if (bits && status) { if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_or(status, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
 
 // Network description as the kernel needs it (wave-uniform).  Aux offsets follow build_geom():
@@ -428,7 +482,7 @@ enum : int { EPI_RELU_CVT = 0, EPI_LAST_FULL = 1, EPI_LAST_DENS = 4, EPI_CVT = 2
 struct Heads {
   float sigma;  // partial dot (this lane group's features)
   float rgb[3];
-  uint32_t fmax;  // fp16 modes: packed running max of |activation high part| bits (range guard)
+  RangeState rs;  // fp16 modes: range guard
 };
 
 // One unit: this wave's 16-sample slice of  acc[16 out x 16 samples] += W_unit[16 x 32] . act[32 x 16]
@@ -460,18 +514,19 @@ __device__ __forceinline__ void load_afrag(const char* p, AFrag& f) {
   f.hi = *reinterpret_cast<const s16x8*>(p);
   if ((PREC & 1) == 0 && PREC != 6) f.lo = *reinterpret_cast<const s16x8*>(p + 1024);
 }
+// acc: main sum (high x high); cor: the correction products (x3 modes; scaled by 2^11 in the fp16 modes)
 template <int PREC>
-__device__ __forceinline__ void unit_mfma_r(const AFrag& a, const Frag& b, f32x4& acc) {
+__device__ __forceinline__ void unit_mfma_r(const AFrag& a, const Frag& b, f32x4& acc, f32x4& cor) {
   constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
   acc = mfma16<F16>(a.hi, b.hi, acc);
   if (X3) {
-    if (PREC != 6) acc = mfma16<F16>(a.lo, b.hi, acc);  // (fp16x2: the weights' low parts are dropped)
-    acc = mfma16<F16>(a.hi, b.lo, acc);
+    if (PREC != 6) cor = mfma16<F16>(a.lo, b.hi, cor);  // (fp16x2: the weights' low parts are dropped)
+    cor = mfma16<F16>(a.hi, b.lo, cor);
   }
 }
 
 template <int PREC>
-__device__ __forceinline__ void unit_mfma(const char* ubase, const Frag& b, f32x4& acc) {
+__device__ __forceinline__ void unit_mfma(const char* ubase, const Frag& b, f32x4& acc, f32x4& cor) {
   constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
 #ifdef FSN_ABL_NOLDS  // timing experiment: operands from registers instead of the LDS ring
   acc = mfma16<F16>(b.lo, b.hi, acc);
@@ -516,9 +571,9 @@ __device__ __forceinline__ void unit_mfma(const char* ubase, const Frag& b, f32x
   if (X3) {
     if (PREC != 6) {
       const s16x8 al = *reinterpret_cast<const s16x8*>(ubase + 1024);
-      acc = mfma16<F16>(al, b.hi, acc);
+      cor = mfma16<F16>(al, b.hi, cor);
     }
-    acc = mfma16<F16>(ah, b.lo, acc);
+    cor = mfma16<F16>(ah, b.lo, cor);
   }
 }
 
@@ -538,9 +593,11 @@ struct NoHook {
 };
 
 // Epilogue of one finished output pair (shared by the compiler-scheduled and the hand-scheduled k-loops).
+// acc0 / acc1: main sums of the pair's two tiles; cor0 / cor1: their correction sums (x3 modes, else unused).
 template <int PREC, int NP_OUT, int EPI, int NOUT, class HK>
 __device__ __forceinline__ void pair_epilogue(const NetDev& net, int tp, const f32x4& acc0, const f32x4& acc1,
-                                              Frag (&out)[NOUT], Heads& heads, int g, HK& hk) {
+                                              const f32x4& cor0, const f32x4& cor1, Frag (&out)[NOUT], Heads& heads,
+                                              int g, HK& hk) {
   constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
 #if defined(FSN_PRIO) && FSN_PRIO == 1
     __builtin_amdgcn_s_setprio(0);
@@ -550,8 +607,22 @@ __device__ __forceinline__ void pair_epilogue(const NetDev& net, int tp, const f
     __builtin_amdgcn_s_setprio(2);
 #endif
     float v[8];
+#ifdef FSN_ABL_OLDEPI  // timing experiment: rounds 1-2's epilogue (no merge, three-instruction split)
+    if constexpr (false) {
+#else
+    if constexpr (X3) {
+#endif
+      // value = main + 2^-11 x corrections (fp16 modes: exact power-of-two unscaling inside the fma); bf16: scale 1
+      constexpr float IK = F16 ? 1.0f / kLoScaleF16 : 1.0f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { v[j] = acc0[j]; v[4 + j] = acc1[j]; }
+      for (int j = 0; j < 4; ++j) {
+        v[j] = __builtin_fmaf(cor0[j], IK, acc0[j]);
+        v[4 + j] = __builtin_fmaf(cor1[j], IK, acc1[j]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] = acc0[j]; v[4 + j] = acc1[j]; }
+    }
     if constexpr (!X3 && EPI == EPI_RELU_CVT && std::is_same<HK, NoHook>::value) {
       // single-pass modes: convert first, ReLU on the packed 16-bit values (sign bit = top bit of either format, so a
       // signed 16-bit max with 0 is the ReLU; rounding keeps the sign, so relu(round(x)) == round(relu(x))):
@@ -563,7 +634,7 @@ __device__ __forceinline__ void pair_epilogue(const NetDev& net, int tp, const f
 #pragma unroll
       for (int i = 0; i < 4; ++i) asm("v_pk_max_i16 %0, %0, 0" : "+v"(w[i]));
       o.hi = __builtin_bit_cast(s16x8, w);
-      if constexpr (F16) range_track<false>(heads.fmax, o.hi);
+      if constexpr (F16) range_track<false>(heads.rs.fmax, o.hi);
       asm volatile("" : "+v"(o.hi));
       return;
     }
@@ -605,13 +676,12 @@ __device__ __forceinline__ void pair_epilogue(const NetDev& net, int tp, const f
       asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
       o = out[0];
 #else
-      // Without a ReLU in front (EPI_CVT) the split would read the MFMA results directly.  hipcc pads the XDL-write ->
-      // VALU-read wait states only for instructions it knows, not for inline asm: the asm form of the split then
-      // reads accumulators whose last MFMA has not retired (found as 1e-3 gradient errors in the backward chain).
-      // The C++ form is used there; behind a ReLU (v_max_i32, padded by hipcc) the asm form is safe.
-      if constexpr (EPI == EPI_CVT) split_store_cpp<F16, X3>(v, o);
-      else split_store<F16, X3>(v, o);
-      if constexpr (F16) range_track<EPI == EPI_CVT || EPI == EPI_NONE>(heads.fmax, o.hi);
+      // The asm form of the split must not read MFMA results directly (hipcc pads the XDL-write -> VALU-read wait
+      // states only for instructions it knows; found as 1e-3 gradient errors in the backward chain).  In the x3
+      // modes v[] comes out of the merge fma above, a compiler-visible VALU instruction; the single-pass modes'
+      // split is plain C++.
+      split_store<F16, X3>(v, o);
+      if constexpr (F16) range_track<EPI == EPI_CVT || EPI == EPI_NONE>(heads.rs.fmax, o.hi);
 #endif
       if (X3) asm volatile("" : "+v"(o.hi), "+v"(o.lo));
       else asm volatile("" : "+v"(o.hi));
@@ -650,26 +720,19 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
 }
 
-// The two pinned accumulator sets of the hand-scheduled path (E = v[240:247], O = v[248:255]; tile 0 / tile 1).
+// The pinned accumulator sets of the hand-scheduled path: main sums E = v[240:247], O = v[248:255] (a pair uses one,
+// the other receives the next pair's bias), corrections C = v[232:239]; tile 0 / tile 1 of each.
 struct AccSets {
-  f32x4 e0, e1, o0, o1;
+  f32x4 e0, e1, o0, o1, c0, c1;
 };
 
-#define FSN_KLOOP_PIN "+{v[240:243]}"(acc.e0), "+{v[244:247]}"(acc.e1), "+{v[248:251]}"(acc.o0), "+{v[252:255]}"(acc.o1)
-#if FSN_KLOOP_NSETS == 4
-#define FSN_KLOOP_SETS_X3                                                                                        \
-  [s0h] "+v"(s0.hi), [s0l] "+v"(s0.lo), [s1h] "+v"(s1.hi), [s1l] "+v"(s1.lo), [s2h] "+v"(s2.hi), [s2l] "+v"(s2.lo), \
-      [s3h] "+v"(s3.hi), [s3l] "+v"(s3.lo), [keep] "=&s"(keep)
-#define FSN_KLOOP_SETS_X2 [s0h] "+v"(s0.hi), [s1h] "+v"(s1.hi), [s2h] "+v"(s2.hi), [s3h] "+v"(s3.hi), [keep] "=&s"(keep)
-#else
+#define FSN_KLOOP_PIN                                                                                              \
+  "+{v[240:243]}"(acc.e0), "+{v[244:247]}"(acc.e1), "+{v[248:251]}"(acc.o0), "+{v[252:255]}"(acc.o1),              \
+      "=&{v[232:235]}"(acc.c0), "=&{v[236:239]}"(acc.c1)
 #define FSN_KLOOP_SETS_X3                                                                                        \
   [s0h] "+v"(s0.hi), [s0l] "+v"(s0.lo), [s1h] "+v"(s1.hi), [s1l] "+v"(s1.lo), [s2h] "+v"(s2.hi), [s2l] "+v"(s2.lo), \
       [keep] "=&s"(keep)
 #define FSN_KLOOP_SETS_X2 [s0h] "+v"(s0.hi), [s1h] "+v"(s1.hi), [s2h] "+v"(s2.hi), [keep] "=&s"(keep)
-#endif
-#define FSN_KLOOP_EPI_OUTS                                                                                    \
-  [oh0] "=&v"(oh[0]), [oh1] "=&v"(oh[1]), [oh2] "=&v"(oh[2]), [oh3] "=&v"(oh[3]), [ol0] "=&v"(ol[0]),          \
-      [ol1] "=&v"(ol[1]), [ol2] "=&v"(ol[2]), [ol3] "=&v"(ol[3]), [fmax] "+v"(fmax), [tmp] "=&v"(tmp)
 #define FSN_B(k) bsel<k, KS_ACT, KS_ENC>(act, enc)
 #define FSN_KLOOP_INS                                                                                            \
   [b0h] "v"(FSN_B(0).hi), [b0l] "v"(FSN_B(0).lo), [b1h] "v"(FSN_B(1).hi), [b1l] "v"(FSN_B(1).lo),                \
@@ -691,22 +754,10 @@ struct AccSets {
   if constexpr (NU == NU_ && OFF == OFF_) {                                                                     \
     constexpr int EV = FSN_KLOOP_##NU_##_##OFF_##_EVENTS, NP = FSN_KLOOP_##NU_##_##OFF_##_PHASES;               \
     kloop_plan<EV, NP>(st, a, mv, gb);                                                                          \
-    if constexpr (EK == 0 && PAR == 0)                                                                          \
+    if constexpr (PAR == 0)                                                                                     \
       FSN_KLOOP_EMIT(FSN_KLOOP_##MODE##_##NU_##_##OFF_##_N0, FSN_KLOOP_PIN FSN_COMMA FSN_KLOOP_SETS_##MODE);    \
-    else if constexpr (EK == 0)                                                                                 \
-      FSN_KLOOP_EMIT(FSN_KLOOP_##MODE##_##NU_##_##OFF_##_N1, FSN_KLOOP_PIN FSN_COMMA FSN_KLOOP_SETS_##MODE);    \
-    else if constexpr (EK == 1 && PAR == 0)                                                                     \
-      FSN_KLOOP_EMIT(FSN_KLOOP_##MODE##_##NU_##_##OFF_##_R0,                                                    \
-                     FSN_KLOOP_PIN FSN_COMMA FSN_KLOOP_SETS_##MODE FSN_COMMA FSN_KLOOP_EPI_OUTS);               \
-    else if constexpr (EK == 1)                                                                                 \
-      FSN_KLOOP_EMIT(FSN_KLOOP_##MODE##_##NU_##_##OFF_##_R1,                                                    \
-                     FSN_KLOOP_PIN FSN_COMMA FSN_KLOOP_SETS_##MODE FSN_COMMA FSN_KLOOP_EPI_OUTS);               \
-    else if constexpr (PAR == 0)                                                                                \
-      FSN_KLOOP_EMIT(FSN_KLOOP_##MODE##_##NU_##_##OFF_##_C0,                                                    \
-                     FSN_KLOOP_PIN FSN_COMMA FSN_KLOOP_SETS_##MODE FSN_COMMA FSN_KLOOP_EPI_OUTS);               \
     else                                                                                                        \
-      FSN_KLOOP_EMIT(FSN_KLOOP_##MODE##_##NU_##_##OFF_##_C1,                                                    \
-                     FSN_KLOOP_PIN FSN_COMMA FSN_KLOOP_SETS_##MODE FSN_COMMA FSN_KLOOP_EPI_OUTS);               \
+      FSN_KLOOP_EMIT(FSN_KLOOP_##MODE##_##NU_##_##OFF_##_N1, FSN_KLOOP_PIN FSN_COMMA FSN_KLOOP_SETS_##MODE);    \
     st.opened(EV);                                                                                              \
   }
 #define FSN_COMMA ,
@@ -733,20 +784,16 @@ __device__ __forceinline__ const Frag& bsel(const Frag (&act)[NACT], const Frag 
   else return enc[kk - KS_ACT];
 }
 
-// One output pair: NU = 2 x k-steps units starting OFF units into the current phase.  The pair accumulates in
-// set E (PAR 0) or O (PAR 1), which holds its bias on entry; the other set receives the next pair's bias (abn =
-// its LDS address).  EK 1 / 2: the other set holds the previous pair's finished accumulators on entry and its
-// epilogue (1: ReLU + fp16 split, 2: split only) runs inside the stream -> prev (high / low parts), fmax.
+// One output pair: NU = 2 x k-steps units starting OFF units into the current phase.  The pair's main sums accumulate
+// in set E (PAR 0) or O (PAR 1), which holds its bias on entry; the other set receives the next pair's bias (abn =
+// its LDS address); the correction sums are written to set C from zero.
 // s0,s1: A sets holding units 0,1 on entry; on exit units NU, NU+1 sit in sets (NU % 3), ((NU+1) % 3) of (s0,s1,s2).
-template <bool F16, bool TWO, int KS_ACT, int KS_ENC, int OFF, int EK, int PAR, int NACT, int NENC>
+template <bool F16, bool TWO, int KS_ACT, int KS_ENC, int OFF, int PAR, int NACT, int NENC>
 __device__ __forceinline__ void kloop_block(WStream& st, const Frag (&act)[NACT], const Frag (&enc)[NENC],
-                                            AccSets& acc, uint32_t abn, AFrag& s0, AFrag& s1, AFrag& s2, AFrag& s3,
-                                            Frag& prev, uint32_t& fmax) {
+                                            AccSets& acc, uint32_t abn, AFrag& s0, AFrag& s1, AFrag& s2) {
   constexpr int NU = 2 * (KS_ACT + KS_ENC);
-  uint32_t a[4], mv[3], keep, tmp;
+  uint32_t a[4], mv[3], keep;
   uint64_t gb[3];
-  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-  u32x4 oh, ol;
   const uint32_t voff = ((threadIdx.x >> 6) ^ FSN_LOADER_XOR) * (kGldsPerWave * 1024) + (threadIdx.x & 63) * 16;
   if constexpr (!TWO) {
     FSN_KLOOP_CASE(X3, 16, 0)
@@ -769,12 +816,7 @@ __device__ __forceinline__ void kloop_block(WStream& st, const Frag (&act)[NACT]
     FSN_KLOOP_CASE(X2, 4, 0)
     FSN_KLOOP_CASE(X2, 4, 4)
   }
-  if constexpr (EK != 0) {
-    prev.hi = __builtin_bit_cast(s16x8, oh);
-    prev.lo = __builtin_bit_cast(s16x8, ol);
-  }
   (void)keep;
-  (void)tmp;
 }
 
 // NP_OUT output pairs (32 features = two 16-row tiles); KS_ACT k-steps (of 32) from `act`, KS_ENC
@@ -790,6 +832,10 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
                                            const Frag (&enc)[NENC], Frag (&out)[NOUT], Heads& heads, ARing& ring,
                                            int g, HK& hk) {
   constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
+  // range guard (fp16 modes): layers whose epilogue forms 16-bit parts close their per-layer maximum; the split modes'
+  // forward passes (bias-initialised accumulators; the backward chain starts from zero) also check the layer's scale
+  constexpr bool kConverts = EPI == EPI_RELU_CVT || EPI == EPI_CVT || EPI == EPI_LAST_FULL;
+  constexpr bool kCheckSmall = X3 && !HK::kZeroInit;
   static_assert(kLead >= 2, "the A-operand prefetch distance (one k-step = two units) must not exceed the phase lead");
   constexpr bool PREFETCH = !X3;
 #ifdef FSN_X3_PF1
@@ -807,75 +853,51 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
                 (KS_ACT == 8 || (KS_ACT == 0 && NP_OUT == 8)) && !HK::kZeroInit) {
     // hand-scheduled path (256-wide networks): ring.cur[0], cur[1] hold this GEMM's units 0 and 1 on entry and the
     // next GEMM's on exit; inside, the three A sets rotate by NU units per pair (compile-time indices).  The pairs
-    // alternate between two pinned accumulator sets; with a plain epilogue (ReLU / none + fp16 split, no hook) the
-    // epilogue of pair tp-1 runs inside the instruction stream of pair tp (kloop_gen.hpp) and only the last pair's
-    // runs on its own.
+    // alternate between two pinned accumulator sets; each pair's epilogue runs right after its block.  (Running the
+    // epilogue of pair tp-1 inside the instruction stream of pair tp - interleaved, or as one burst for waves 4..7
+    // only - was measured slower, DESIGN.md 4.3, and is no longer generated.)
     constexpr int NU = 2 * KS;
     static_assert(TOTAL % UPP == 0, "a GEMM of the hand-scheduled path ends on a phase boundary");
-    // Deferred epilogue (kloop_gen.hpp, R / C variants): the epilogue of pair tp-1 runs as one burst in the middle of
-    // pair tp's instruction stream.  Only waves 4..7 do this; their SIMD partners (waves 0..3) run each pair's
-    // epilogue right after the pair, so on every SIMD the two epilogues are half a pair apart and each coincides
-    // with the partner's MFMAs instead of with the partner's epilogue (all waves are kept in step by the weight
-    // stream's barriers).  Interleaving the epilogue one instruction per MFMA was measured slower (no issue slots
-    // to spare beside two waves' MFMAs, A reads and waits).
-#ifndef FSN_DEFER_EPI  // (measured slower too: 435 ms against 420 ms per frame; kept as an experiment switch)
-    constexpr bool kCanDefer = false;
-#else
-    constexpr bool kCanDefer = F16 && std::is_same<HK, NoHook>::value && (EPI == EPI_RELU_CVT || EPI == EPI_CVT) && KS > 2;
-#endif
-    constexpr int EKD = EPI == EPI_RELU_CVT ? 1 : 2;
+    static_assert(kNS == 3, "three A register sets");
     AccSets acc;
     acc.e0 = *reinterpret_cast<const f32x4*>(bias + 4 * g);
     acc.e1 = *reinterpret_cast<const f32x4*>(bias + 16 + 4 * g);
     acc.o0 = acc.e0;
     acc.o1 = acc.e1;
     const uint32_t bias_lds = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)(bias + 4 * g);
-    auto run = [&](auto EKS_) __attribute__((always_inline)) {
-      constexpr int EKS = decltype(EKS_)::value;  // 0: epilogue after each pair; 1 / 2: deferred into the next pair
-      static_for<NP_OUT>([&](auto TP) __attribute__((always_inline)) {
-        constexpr int tp = decltype(TP)::value;
-        constexpr int NS = kNS;  // A register sets
-        constexpr int R0 = (tp * NU) % NS, OFF = (tp * NU) % UPP, PAR = tp & 1;
-        constexpr int EK = tp == 0 ? 0 : EKS;
-        hk.pre(tp);
+    static_for<NP_OUT>([&](auto TP) __attribute__((always_inline)) {
+      constexpr int tp = decltype(TP)::value;
+      constexpr int NS = kNS;  // A register sets
+      constexpr int R0 = (tp * NU) % NS, OFF = (tp * NU) % UPP, PAR = tp & 1;
+      hk.pre(tp);
 #if defined(FSN_PRIO) && FSN_PRIO == 4
-        if (__builtin_amdgcn_readfirstlane(threadIdx.x) & 256) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+      if (__builtin_amdgcn_readfirstlane(threadIdx.x) & 256) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
 #endif
 #ifdef FSN_STAMP
-        const uint64_t ts0 = __builtin_amdgcn_s_memtime();
+      const uint64_t ts0 = __builtin_amdgcn_s_memtime();
 #endif
-        const uint32_t abn = bias_lds + 128u * (tp + 1 < NP_OUT ? tp + 1 : tp);  // (last pair: a harmless reload)
-        kloop_block<F16, PREC == 6, KS_ACT, KS_ENC, OFF, EK, PAR>(
-            st, act, enc, acc, abn, ring.cur[R0], ring.cur[(R0 + 1) % NS], ring.cur[(R0 + 2) % NS],
-            ring.cur[NS > 3 ? (R0 + 3) % NS : 0], out[tp > 0 && tp - 1 < NOUT ? tp - 1 : 0], heads.fmax);
+      const uint32_t abn = bias_lds + 128u * (tp + 1 < NP_OUT ? tp + 1 : tp);  // (last pair: a harmless reload)
+      kloop_block<F16, PREC == 6, KS_ACT, KS_ENC, OFF, PAR>(st, act, enc, acc, abn, ring.cur[R0], ring.cur[(R0 + 1) % NS],
+                                                            ring.cur[(R0 + 2) % NS]);
 #ifdef FSN_STAMP
-        const uint64_t ts1 = __builtin_amdgcn_s_memtime();
+      const uint64_t ts1 = __builtin_amdgcn_s_memtime();
 #endif
-        if constexpr (EKS == 0 || tp == NP_OUT - 1) {
-          if constexpr (PAR == 0) pair_epilogue<PREC, NP_OUT, EPI>(net, tp, acc.e0, acc.e1, out, heads, g, hk);
-          else pair_epilogue<PREC, NP_OUT, EPI>(net, tp, acc.o0, acc.o1, out, heads, g, hk);
+      if constexpr (PAR == 0) pair_epilogue<PREC, NP_OUT, EPI>(net, tp, acc.e0, acc.e1, acc.c0, acc.c1, out, heads, g, hk);
+      else pair_epilogue<PREC, NP_OUT, EPI>(net, tp, acc.o0, acc.o1, acc.c0, acc.c1, out, heads, g, hk);
+#ifdef FSN_STAMP
+      {
+        const uint64_t ts2 = __builtin_amdgcn_s_memtime();
+        if (KS == 8) {  // the 256 -> 256 GEMMs
+          st.t_k += ts1 - ts0;
+          st.t_e += ts2 - ts1;
+          st.t_n += 1;
+        } else {  // first layer, skip layer, branch
+          st.t_ko += ts1 - ts0;
+          st.t_eo += ts2 - ts1;
         }
-#ifdef FSN_STAMP
-        {
-          const uint64_t ts2 = __builtin_amdgcn_s_memtime();
-          if (KS == 8) {  // the 256 -> 256 GEMMs
-            st.t_k += ts1 - ts0;
-            st.t_e += ts2 - ts1;
-            st.t_n += 1;
-          } else {  // first layer, skip layer, branch
-            st.t_ko += ts1 - ts0;
-            st.t_eo += ts2 - ts1;
-          }
-        }
+      }
 #endif
-      });
-    };
-    if constexpr (kCanDefer) {
-      if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) run(std::integral_constant<int, EKD>{});
-      else run(std::integral_constant<int, 0>{});
-    } else {
-      run(std::integral_constant<int, 0>{});
-    }
+    });
     // bring the sets holding the next GEMM's first kKD units back to cur[0..kKD-1]
     constexpr int RE = TOTAL % kNS;
     if constexpr (RE != 0) {
@@ -885,11 +907,13 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
 #pragma unroll
       for (int i = 0; i < kNS; ++i) ring.cur[i] = t[i];
     }
+    if constexpr (F16 && kConverts) range_layer_end<kCheckSmall>(heads.rs);
     return;
   }
 #pragma unroll
   for (int tp = 0; tp < NP_OUT; ++tp) {
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 cor0 = {0.f, 0.f, 0.f, 0.f}, cor1 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (!HK::kZeroInit) {
       acc0 = *reinterpret_cast<const f32x4*>(bias + 32 * tp + 4 * g);
       acc1 = *reinterpret_cast<const f32x4*>(bias + 32 * tp + 16 + 4 * g);
@@ -921,8 +945,8 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
                                       : st.n_base + (v - TOTAL) * UB;
         load_afrag<PREC>(src, nxt[0]);
         load_afrag<PREC>(src + UB, nxt[1]);
-        unit_mfma_r<PREC>(ring.cur[0], b, acc0);
-        unit_mfma_r<PREC>(ring.cur[1], b, acc1);
+        unit_mfma_r<PREC>(ring.cur[0], b, acc0, cor0);
+        unit_mfma_r<PREC>(ring.cur[1], b, acc1, cor1);
         ring.cur[0] = nxt[0];
         ring.cur[1] = nxt[1];
         __builtin_amdgcn_sched_group_barrier(0x100, X3 ? 4 : 2, 0);  // DS reads
@@ -940,8 +964,8 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
                                         : st.n_base + (v - TOTAL) * UB;
           AFrag nxt;
           load_afrag<PREC>(src, nxt);
-          if (sub == 0) unit_mfma_r<PREC>(ring.cur[0], b, acc0);
-          else unit_mfma_r<PREC>(ring.cur[0], b, acc1);
+          if (sub == 0) unit_mfma_r<PREC>(ring.cur[0], b, acc0, cor0);
+          else unit_mfma_r<PREC>(ring.cur[0], b, acc1, cor1);
           ring.cur[0] = nxt;
           __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS reads
           __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);  // MFMAs
@@ -955,13 +979,14 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
           if (((u + kLead) % UPP == 0 && u + kLead <= TOTAL) || (u + kLead == TOTAL && TOTAL % UPP != 0)) st.open_next();
           if (u % UPP == 0) st.enter_phase();
           const char* ub = st.c_base + (u % UPP) * UB;
-          if (sub == 0) unit_mfma<PREC>(ub, b, acc0);
-          else unit_mfma<PREC>(ub, b, acc1);
+          if (sub == 0) unit_mfma<PREC>(ub, b, acc0, cor0);
+          else unit_mfma<PREC>(ub, b, acc1, cor1);
         }
       }
     }
-    pair_epilogue<PREC, NP_OUT, EPI>(net, tp, acc0, acc1, out, heads, g, hk);
+    pair_epilogue<PREC, NP_OUT, EPI>(net, tp, acc0, acc1, cor0, cor1, out, heads, g, hk);
   }
+  if constexpr (F16 && kConverts) range_layer_end<kCheckSmall>(heads.rs);
 }
 
 template <int PREC, int NP_OUT, int KS_ACT, int KS_ENC, int EPI, int NACT, int NENC, int NOUT>
@@ -1023,8 +1048,8 @@ __device__ __forceinline__ void gemm_layer2(WStream& st, const NetDev& net, int 
     // asm - gained 0.9 % and was NOT safe: hipcc does not see the XDL hazards of registers an asm statement touches,
     // and the bf16 density pass came out different from run to run.  tests/test_parity_fp64.py now renders the
     // same rays alone and inside a frame in this mode too.)
-    pair_epilogue<PREC, NP_OUT, EPI>(net, tp, a00, a01, out0, heads0, g, hk);
-    pair_epilogue<PREC, NP_OUT, EPI>(net, tp, a10, a11, out1, heads1, g, hk);
+    pair_epilogue<PREC, NP_OUT, EPI>(net, tp, a00, a01, a00, a01, out0, heads0, g, hk);  // (single pass: no corrections)
+    pair_epilogue<PREC, NP_OUT, EPI>(net, tp, a10, a11, a10, a11, out1, heads1, g, hk);
   }
 }
 
@@ -1040,7 +1065,7 @@ __device__ __forceinline__ void mlp_tile2(WStream& st, const NetDev& net, const 
   const float* misc = net.aux + (L + 5) * D;
   Frag A0[NA], A1[NA], B0[NA], B1[NA];
   Frag none[1];
-  Heads h0{0.f, {0.f, 0.f, 0.f}, 0u}, h1{0.f, {0.f, 0.f, 0.f}, 0u};
+  Heads h0{0.f, {0.f, 0.f, 0.f}, {0u, 0u, 0u}}, h1{0.f, {0.f, 0.f, 0.f}, {0u, 0u, 0u}};
   auto enc_pos = [&](Frag (&p0)[kKsPos], Frag (&p1)[kKsPos]) __attribute__((always_inline)) {
     float x, y, z;
     src0.pos(x, y, z);
@@ -1099,8 +1124,10 @@ __device__ __forceinline__ void mlp_tile2(WStream& st, const NetDev& net, const 
     }
   }
   if constexpr (F16) {
-    asm("v_pk_max_u16 %0, %0, %1" : "+v"(h0.fmax) : "v"(h1.fmax));
-    range_report(net.status, h0.fmax);
+    // (single pass: one running maximum per group for the whole tile, no per-layer scale check)
+    asm("v_pk_max_u16 %0, %0, %1" : "+v"(h0.rs.fmax) : "v"(h1.rs.fmax));
+    range_layer_end<false>(h0.rs);
+    range_report(net.status, h0.rs);
   }
 }
 
@@ -1153,7 +1180,7 @@ __device__ __forceinline__ void mlp_tile(WStream& st, const NetDev& net, const S
   const float* misc = net.aux + (L + 5) * D;
   Frag A[NA], B[NA];
   Frag none[1];
-  Heads heads{0.f, {0.f, 0.f, 0.f}, 0u};
+  Heads heads{0.f, {0.f, 0.f, 0.f}, {0u, 0u, 0u}};
   {
     Frag pe[kKsPos];
     float px, py, pz;
@@ -1217,7 +1244,10 @@ __device__ __forceinline__ void mlp_tile(WStream& st, const NetDev& net, const S
       rgb[c] = 1.0f / (1.0f + expf(-z));  // sigmoid (models.py:135)
     }
   }
-  if constexpr (F16) range_report(net.status, heads.fmax);
+  if constexpr (F16) {
+    range_layer_end<false>(heads.rs);  // (single-pass modes keep one running maximum)
+    range_report(net.status, heads.rs);
+  }
 }
 
 template <int NT, int PREC, bool FULL, class Src>

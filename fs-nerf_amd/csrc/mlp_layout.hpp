@@ -35,6 +35,14 @@ constexpr int kMaxLayers = 16;
 
 FSN_HD bool prec_is_x3(int prec) { return (prec & 1) == 0; }
 FSN_HD bool prec_is_f16(int prec) { return prec >= 2; }
+// Low parts of the split fp16 modes (weights in the blob, activations in registers and in the training workspace) are
+// stored SCALED: low = fp16((v - high) * 2^11).  The unscaled remainder of a value below ~0.1 is an fp16 subnormal
+// (fixed 2^-24 resolution: an activation of 1e-3 kept ~15 bits, a sigma error of 4e-4); scaled it is a normal fp16
+// number down to |v| ~ 6e-5 (and still carries 2^-36 absolute below that).  The two correction products al.wh, ah.wl
+// are summed in their own accumulator and folded in as 2^-11 * corr by the epilogue.  bf16 has float32's exponent
+// range: scale 1.
+constexpr float kLoScaleF16 = 2048.0f;
+FSN_HD float lo_scale(int prec) { return (prec_is_f16(prec) && prec_is_x3(prec)) ? kLoScaleF16 : 1.0f; }
 FSN_HD int unit_bytes(int prec) { return prec_is_x3(prec) ? 2048 : 1024; }
 FSN_HD int units_per_phase(int prec) { return kPhaseBytes / unit_bytes(prec); }
 

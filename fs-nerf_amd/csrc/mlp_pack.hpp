@@ -44,7 +44,7 @@ FSN_HD void pack_piece(const PackArgs& a, int64_t piece, uint16_t out8[8]) {
     const float w = W[(int64_t)row * Lg.ld + col];
     const bool f16 = prec_is_f16(a.prec);
     const uint16_t hi = half_rne(w, f16);
-    out8[j] = part == 0 ? hi : half_rne(w - half_to_f32(hi, f16), f16);
+    out8[j] = part == 0 ? hi : half_rne((w - half_to_f32(hi, f16)) * lo_scale(a.prec), f16);
   }
 }
 
@@ -70,7 +70,8 @@ FSN_HD float aux_value(const PackArgs& a, int i) {
 
 FSN_HD void header_words(const PackArgs& a, uint32_t hw[64]) {
   for (int i = 0; i < 64; ++i) hw[i] = 0;
-  hw[0] = kBlobMagic; hw[1] = 1; hw[2] = (uint32_t)a.prec; hw[3] = (uint32_t)a.n_layers;
+  hw[0] = kBlobMagic; hw[1] = 2;  // layout version 2: scaled low parts (mlp_layout.hpp, lo_scale)
+  hw[2] = (uint32_t)a.prec; hw[3] = (uint32_t)a.n_layers;
   hw[4] = (uint32_t)a.d_hidden; hw[5] = a.skip_mask; hw[6] = (uint32_t)a.n_freqs_pos;
   hw[7] = (uint32_t)a.n_freqs_dir; hw[8] = (uint32_t)a.G.units_total; hw[9] = (uint32_t)a.G.nph_full;
   hw[10] = (uint32_t)a.G.nph_density; hw[11] = (uint32_t)a.G.aux_off; hw[12] = (uint32_t)a.G.aux_floats;

@@ -269,7 +269,7 @@ __global__ void k_pack_bwd(BwdPackArgs a, char* __restrict__ stream, int64_t n_p
       const int oc = 32 * ks + 16 * (j >> 2) + 4 * grp + (j & 3);
       const float w = W[(int64_t)oc * ld + row];
       const uint16_t hi = half_rne(w, f16);
-      o8[j] = part == 0 ? hi : half_rne(w - half_to_f32(hi, f16), f16);
+      o8[j] = part == 0 ? hi : half_rne((w - half_to_f32(hi, f16)) * lo_scale(a.prec), f16);
     }
   }
   uint4 v;
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(kThreads) void k_train_bwd(TrainBwdArgs a) {
   const float scale = a.scale ? a.scale[0] : 1.0f;
   ARing ring;
   prime_ring<PREC>(st, ring);
-  Heads heads{0.f, {0.f, 0.f, 0.f}, 0u};
+  Heads heads{0.f, {0.f, 0.f, 0.f}, {0u, 0u, 0u}};
   Frag none[1];
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t s = tile * kTC + col;
@@ -428,7 +428,10 @@ __global__ __launch_bounds__(kThreads) void k_train_bwd(TrainBwdArgs a) {
         gemm_layer<PREC, NT, NT, 0, EPI_CVT>(st, net, 0, A, none, B, heads, ring, g, hk);
       }
     }
-    if constexpr (F16) range_report(net.status, heads.fmax);  // a scaled gradient left the fp16 range
+    if constexpr (F16) {  // a scaled gradient left the fp16 range
+      range_layer_end<false>(heads.rs);
+      range_report(net.status, heads.rs);
+    }
   }
   st.drain();
 }
@@ -453,6 +456,19 @@ __device__ __forceinline__ f32x16 mfma32(const s16x8& a, const s16x8& b, const f
   if (F16)
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// The savers store the fp16 modes' low parts scaled by 2^11 (mlp_layout.hpp, kLoScaleF16).  This kernel keeps ONE
+// accumulator block per workgroup (128 of its 256 registers), so it cannot sum the correction products separately:
+// it multiplies the low-part dwords by 2^-11 as packed fp16 on load (exact unless the result is subnormal, in which
+// case it is the value rounds 1-2 stored).  Gradients are asserted to 2e-4 of a tensor's largest entry, far above that.
+template <bool F16X3>
+__device__ __forceinline__ u32x4 unscale_lo(u32x4 w) {
+  if constexpr (F16X3) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm("v_pk_mul_f16 %0, %0, %1" : "+v"(w[i]) : "s"(0x10001000u));  // 2^-11 | 2^-11
+  }
+  return w;
 }
 
 // the two rows of a pair-row out of 8 packed dwords (8 samples): low halves -> row 2q, high halves -> row 2q+1
@@ -568,7 +584,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_wgrad(WgArgs a) {  // (2 waves p
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
           s16x8 ev, od;
-          unzip_rows(braw[it][pl][0], braw[it][pl][1], ev, od);
+          if (pl == 1) unzip_rows(unscale_lo<F16 && X3>(braw[it][pl][0]), unscale_lo<F16 && X3>(braw[it][pl][1]), ev, od);
+          else unzip_rows(braw[it][pl][0], braw[it][pl][1], ev, od);
           const int R = 2 * PR;  // rows R (even) and R + 1 (odd) sit next to each other in a tile's operand image
           const int addr = ((((R >> 5) * 2 + (sg & 1)) * 64) + (sg >> 1) * 32 + (R & 31)) * 16;  // sg = 2 kg + ks
           *reinterpret_cast<s16x8*>(&lds[buf][pl][addr]) = ev;
@@ -592,7 +609,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_wgrad(WgArgs a) {  // (2 waves p
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       unzip_rows(araw[ks][0][0], araw[ks][0][1], af[0][ks].hi, af[1][ks].hi);
-      if (X3) unzip_rows(araw[ks][1][0], araw[ks][1][1], af[0][ks].lo, af[1][ks].lo);
+      if (X3) unzip_rows(unscale_lo<F16>(araw[ks][1][0]), unscale_lo<F16>(araw[ks][1][1]), af[0][ks].lo, af[1][ks].lo);
     }
     if (want_bias) {
 #pragma unroll
@@ -733,9 +750,10 @@ __global__ __launch_bounds__(kThreads) void k_heads_wgrad(HeadsArgs a) {
     for (int sidx = 0; sidx < 2; ++sidx) {
       v[0][sidx] = from_h<F16>((short)(h[sidx] & 0xffffu));
       v[1][sidx] = from_h<F16>((short)(h[sidx] >> 16));
-      if (X3) {
-        v[0][sidx] += from_h<F16>((short)(l[sidx] & 0xffffu));
-        v[1][sidx] += from_h<F16>((short)(l[sidx] >> 16));
+      if (X3) {  // (fp16: the low parts are stored scaled by 2^11)
+        constexpr float IK = F16 ? 1.0f / kLoScaleF16 : 1.0f;
+        v[0][sidx] = __builtin_fmaf(from_h<F16>((short)(l[sidx] & 0xffffu)), IK, v[0][sidx]);
+        v[1][sidx] = __builtin_fmaf(from_h<F16>((short)(l[sidx] >> 16)), IK, v[1][sidx]);
       }
     }
   };

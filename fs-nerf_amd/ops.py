@@ -188,14 +188,28 @@ def status_word(device) -> Tensor:
     return w
 
 
-def range_ok(device) -> bool:
-    """False when a launch since the last call reported an activation (or scaled gradient) outside the fp16 range;
-    the word is cleared.  Reads 4 bytes back: one host sync."""
+def range_flags(device) -> int:
+    """FSN_STATUS_* bits reported by the launches since the last call (0 = all inside the fp16 modes' envelope); the
+    word is cleared.  Reads 4 bytes back: one host sync."""
     w = status_word(device)
-    bad = bool(int(w.item()) & L.FSN_STATUS_FP16_RANGE)
-    if bad:
+    bits = int(w.item()) & (L.FSN_STATUS_FP16_RANGE | L.FSN_STATUS_FP16_SMALL)
+    if bits:
         w.zero_()
-    return not bad
+    return bits
+
+
+def range_ok(device) -> bool:
+    """False when a launch since the last call reported values outside the fp16 modes' envelope (either end)."""
+    return range_flags(device) == 0
+
+
+def describe_flags(bits: int) -> str:
+    what = []
+    if bits & L.FSN_STATUS_FP16_RANGE:
+        what.append("values reached the top of the fp16 range (|v| >= 65504)")
+    if bits & L.FSN_STATUS_FP16_SMALL:
+        what.append("a layer's activations were all below 2^-14 (below the split's float32-grade envelope)")
+    return " and ".join(what) if what else "inside the envelope"
 
 
 

@@ -141,10 +141,11 @@ def _fused_launch(rays_o, rays_d, camera, estimator, model, model_fine, train, b
 
     out = launch()
     nets = [m for m in {id(model): model, id(fine): fine}.values()]
-    if any(m.range_check and m.fp16_family(m.PRECISIONS[m.precision]) for m in nets) and not ops.range_ok(dev):
+    bits = ops.range_flags(dev) if any(m.range_check and m.fp16_family(m.PRECISIONS[m.precision]) for m in nets) else 0
+    if bits:
         for m in nets:  # the coarse and the fine pass run in one precision mode
             if m.fp16_family(m.PRECISIONS[m.precision]):
-                m.fall_back("render_rays")
+                m.fall_back("render_rays", bits)
         out = launch()
     return out
 

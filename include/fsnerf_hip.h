@@ -38,8 +38,9 @@ typedef void* fsn_stream_t; /* hipStream_t */
 #define FSN_PREC_BF16 1   /* single bf16 MFMA pass, fp32 accumulate (BASELINE config 5).  The single-pass modes round
                              every operand to 16 bits and evaluate the encodings' sines with the hardware
                              instruction (|err| ~1e-4 rad, below that rounding) */
-#define FSN_PREC_FP16X3 2 /* split-fp16 (hi+lo) x 3 MFMA passes: fp32-grade accuracy; |activation| must stay
-                             below 65504 (fp16 range) - the default "parity" mode */
+#define FSN_PREC_FP16X3 2 /* split-fp16 (hi + 2^-11 lo') x 3 MFMA passes, the two correction products in their own
+                             accumulator: fp32-grade accuracy for layer scales from 2^-14 (6.1e-5) up to 65504 (both ends
+                             reported through `status`, below) - the default "parity" mode */
 #define FSN_PREC_FP16 3   /* single fp16 MFMA pass */
 #define FSN_PREC_FP16X2 6 /* two fp16 MFMA passes: activations high+low parts, weights' high part only (the x3 blob
                              layout; inference only).  Measured accuracy in DESIGN.md - not the parity mode */
@@ -48,8 +49,13 @@ typedef void* fsn_stream_t; /* hipStream_t */
  * uint32_t owned by the caller (or NULL = no report).  A kernel sets bit 0 (atomic OR, never clears) when a hidden
  * activation - or, in the training backward, a scaled gradient - reached fp16 infinity, i.e. left the range in
  * which FSN_PREC_FP16X3 / _FP16 / _FP16X2 are valid; the results of that launch are then not to be used (re-run in
- * FSN_PREC_BF16X3, which has the range of float32).  The bf16 modes never set it. */
+ * FSN_PREC_BF16X3, which has the range of float32).  Bit 1 is the other end of the envelope of the split modes
+ * (FSN_PREC_FP16X3 / _FP16X2, forward passes): in some layer the largest |activation| over a wavefront's 16 samples x
+ * all features was non-zero but below 2^-14 (an fp16 subnormal); high + scaled low part then no longer carry 22 bits
+ * relative to the layer's scale - results are finite and still ~bf16x3-grade, the caller decides (the Python host
+ * re-runs in FSN_PREC_BF16X3).  The bf16 modes set neither bit. */
 #define FSN_STATUS_FP16_RANGE 1u
+#define FSN_STATUS_FP16_SMALL 2u
 
 int fsn_version(void);
 const char* fsn_last_error(void);

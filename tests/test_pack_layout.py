@@ -46,6 +46,7 @@ class Emu:
     def __init__(self, blob, prec):
         hw = blob[:256].view(np.uint32)
         assert hw[0] == 0x4E53460A
+        assert hw[1] == 2, "blob layout version 2: fp16 low parts scaled by 2^11 (csrc/mlp_layout.hpp, lo_scale)"
         self.prec, self.L, self.D = int(hw[2]), int(hw[3]), int(hw[4])
         self.skip_mask, self.nf, self.nfd = int(hw[5]), int(hw[6]), int(hw[7])
         self.units_total, self.nph_full, self.nph_density = int(hw[8]), int(hw[9]), int(hw[10])
@@ -63,7 +64,8 @@ class Emu:
             (lambda b: bf16_to_f32(b.view(np.uint16)))
         hi = dec(self.stream[base:base + 1024]).reshape(64, 8).astype(np.float64)
         if self.prec in (0, 2):
-            hi = hi + dec(self.stream[base + 1024:base + 2048]).reshape(64, 8)
+            lo_scale = 2048.0 if self.prec == 2 else 1.0  # fp16 low parts are stored as fp16((w - hi) * 2^11)
+            hi = hi + dec(self.stream[base + 1024:base + 2048]).reshape(64, 8).astype(np.float64) / lo_scale
         self.unit += 1
         return hi
 

@@ -211,13 +211,13 @@ def hidden_max(sd, x, L):
     return mx
 
 
-@pytest.mark.parametrize("scale,factor", [(1e2, 3.0), (1e4, 40.0)])
+@pytest.mark.parametrize("scale,factor", [(1e2, 3.0), (1e4, 3.0)])
 def test_fp16x3_envelope_large_activations(dev, scale, factor):
     """Trained networks have activations far above the default initialisation's ~1: with hidden activations of 1e2
-    and 1e4 (still inside the fp16 range) the parity mode must stay inside 1e-4, end to end.  At 1e2 it is still
-    float32-grade (3 x the float32 oracle's error).  At 1e4 the test network's sigma / connection weights are
-    ~2e-5, i.e. fp16-subnormal: their low parts fall below fp16's 6e-8 resolution and the error grows to ~5e-6
-    (rgb_map; measured), 20 x inside the bar - the documented envelope of the mode."""
+    and 1e4 (still inside the fp16 range) the parity mode must stay float32-grade (3 x the float32 oracle's error),
+    end to end.  At 1e4 the test network's sigma / connection weights are ~2e-5, i.e. fp16-subnormal high parts: until
+    round 3 their low parts fell below fp16's 6e-8 resolution (error 5e-6 on rgb_map, asserted at 40 x); the low parts
+    are now stored scaled by 2^11 (csrc/mlp_layout.hpp) and the case is float32-grade like the others."""
     from fs_nerf_amd.render import rendering as Rm
     L, D, R, S, NI = 8, 256, 192, 64, 128
     o, d, gen = orbit_rays(R, 11, 800, 1111.111)
@@ -237,6 +237,75 @@ def test_fp16x3_envelope_large_activations(dev, scale, factor):
             hip = Rm.render_rays(o, d, est, mc, white_bkgd=True, device=dev, model_fine=mf, u=u.to(dev), u_fine=uf.to(dev))
     assert mc.precision == "fp16x3" and mf.precision == "fp16x3"
     assert_parity(hip, o32, truth, f"activations ~{scale:g}", factor=factor)
+
+
+@pytest.mark.parametrize("s", [1e-1, 1e-2, 1e-3, 1e-4])
+def test_fp16x3_envelope_small_activations(dev, s):
+    """The LOW end of the envelope (the reference's weight-norm regulariser pushes this way).
+    Hidden activations ~ s x the default initialisation's.  Unscaled fp16 low parts are subnormal below ~0.1 (an
+    activation of 1e-3 kept ~15 bits: sigma errors of 4e-4 relative, silently); with the low parts scaled by 2^11 and
+    the correction products in their own accumulator the mode is float32-grade natively down to s = 1e-3 (layer
+    maxima 1e-4 .. 2e-3), checked here END TO END on the headline shape with the same criterion as everywhere else.
+    Below that the kernels REPORT it (FSN_STATUS_FP16_SMALL: a layer whose largest activation over a wavefront's 16
+    samples is an fp16 subnormal, < 2^-14) and the host re-runs in bf16x3 with a RuntimeWarning - checked to bf16x3's
+    stated accuracy.  Either way never silent."""
+    from fs_nerf_amd.render import rendering as Rm
+    L, D, R, S, NI = 8, 256, 192, 64, 128
+    o, d, gen = orbit_rays(R, 13, 800, 1111.111)
+    u, uf = torch.rand(R, generator=gen), torch.rand(R, NI, generator=gen)
+    sd_c, sd_f = scaled_sd(L, D, 42, s), scaled_sd(L, D, 43, s)
+    x = o[:, None, :] + d[:, None, :] * torch.linspace(2.0, 6.0, 16)[None, :, None]
+    hm = hidden_max(sd_f, x.reshape(-1, 3), L)
+    assert 0.3 * s < hm < 30 * s, f"test net: hidden max {hm:.3g} for s {s:g}"
+    kw = dict(near=2.0, far=6.0, n_samples=S, n_importance=NI, u=u, u_fine=uf, white_bkgd=True)
+    truth = oracle(o, d, sd_c, sd_f, cfg_of(L), torch.float64, **kw)
+    o32 = oracle(o, d, sd_c, sd_f, cfg_of(L), torch.float32, **kw)
+    mc, mf = hip_model(sd_c, L, D, dev, "fp16x3"), hip_model(sd_f, L, D, dev, "fp16x3")
+    est = Rm.StratifiedEstimator(2.0, 6.0, S, NI)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        with torch.no_grad():
+            hip = Rm.render_rays(o, d, est, mc, white_bkgd=True, device=dev, model_fine=mf, u=u.to(dev), u_fine=uf.to(dev))
+    fell_back = mc.precision == "bf16x3"
+    if s >= 1e-3:
+        assert not fell_back and not rec, f"s={s:g} is inside the native envelope (hidden max {hm:.3g})"
+    if fell_back:
+        assert mf.precision == "bf16x3" and any("below 2^-14" in str(w.message) for w in rec), "reported, not silent"
+        # (bf16x3's own grade, ~2^-16 per product whatever the scale: 4 x the absolute floors here - measured: one
+        # weight of 36,864 at 3.3e-5 - against 3 x on the default-scale nets of test_end_to_end_bf16x3_fallback_mode)
+        assert_parity(hip, o32, truth, f"activations ~{s:g}, reported bf16x3 re-run", factor=10.0, atol_scale=4.0)
+    else:
+        assert not rec
+        assert_parity(hip, o32, truth, f"activations ~{s:g}, native fp16x3", factor=3.0)
+    if s <= 1e-4:
+        assert fell_back, "below the envelope the mode must say so"
+
+
+@pytest.mark.parametrize("s", [1e4, 1e2, 1.0, 1e-1, 1e-2, 1e-3])
+def test_fp16x3_sigma_relative_error_over_the_envelope(dev, s):
+    """NeRF.forward alone, 20,000 points, the density head's RELATIVE error (a weight's error is of the same order):
+    fp16x3 within 4 x the float32 oracle's error against a float64 evaluation over the whole native envelope
+    (tools/emulate_split.py tabulates the same arithmetic on the CPU: rounds 1-2 had 3e-3 at s = 1e-2)."""
+    L, D, n = 8, 256, 20000
+    gen = torch.Generator().manual_seed(0)
+    x = torch.rand(n, 3, generator=gen) * 3.0 - 1.5
+    dv = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1)
+    sd = scaled_sd(L, D, 42, s)
+    want = O.nerf_forward({k: v.double() for k, v in sd.items()}, x.double(), dv.double(), **cfg_of(L))
+    o32 = O.nerf_forward(sd, x, dv, **cfg_of(L)).double()
+    m = hip_model(sd, L, D, dev, "fp16x3")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        with torch.no_grad():
+            y = m(x.to(dev), dv.to(dev)).cpu().double()
+    assert m.precision == "fp16x3"
+    den = want[:, 3].abs().clamp_min(1e-2 * float(want[:, 3].abs().max()))
+    es, e32 = ((y[:, 3] - want[:, 3]).abs() / den), ((o32[:, 3] - want[:, 3]).abs() / den)
+    assert float(es.max()) <= 4.0 * float(e32.max()) and float(es.mean()) <= 2.0 * float(e32.mean()), \
+        f"s={s:g}: sigma rel. error max {float(es.max()):.2e} mean {float(es.mean()):.2e} vs float32 oracle " \
+        f"{float(e32.max()):.2e} / {float(e32.mean()):.2e}"
+    er, er32 = (y[:, :3] - want[:, :3]).abs(), (o32[:, :3] - want[:, :3]).abs()
+    assert float(er.max()) <= 4.0 * float(er32.max()) + 1e-7, (s, float(er.max()), float(er32.max()))
 
 
 def test_fp16x3_out_of_range_is_detected_and_rerun_in_bf16x3(dev):

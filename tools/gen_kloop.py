@@ -11,21 +11,25 @@ bookkeeping per 1536-cycle pair).  The streams below
   * keep D = 2 units of A operands in flight ahead of the MFMAs in a three-set register rotation, with counted
     lgkmcnt waits;
   * carry the weight-phase openings (counted vmcnt + s_barrier + this wave's two LDS-DMA loads) at their fixed places;
-  * interleave, one instruction per MFMA, the epilogue of the PREVIOUS pair (whose accumulators sit in the other of
-    two pinned register sets) and the bias load of the NEXT pair (into that set once the epilogue has consumed it).
+  * load the bias of the NEXT pair into the other of two pinned accumulator sets behind the MFMAs;
+  * keep the two CORRECTION products of the split (al.wh, ah.wl) in their own accumulator set C = v[232:239]: the low
+    parts of the fp16 modes are stored scaled by 2^11 (mlp_layout.hpp, kLoScaleF16) so that they stay normal fp16
+    numbers for activations down to ~1e-4; the pair's epilogue folds 2^-11 * C into the main sums.  (The epilogue of
+    a pair runs in C++ after its block; running it inside the next block's stream was measured slower)
 One macro = one output pair (32 features x 16 samples of a wave) of one GEMM.
 
-Naming: FSN_KLOOP_<MODE>_<NU>_<OFF>_<EPI><PAR>(MFMA)
-  MODE  X3 (a.w = ah.wh + al.wh + ah.wl) or X2 (weights' low parts dropped)
+Naming: FSN_KLOOP_<MODE>_<NU>_<OFF>_N<PAR>(MFMA)
+  MODE  X3 (a.w = ah.wh + [al.wh + ah.wl]) or X2 (weights' low parts dropped: ah.wh + [ah.wl] in operand terms)
   NU    units in the pair (2 x k-steps), OFF = units between the start of the current phase and the pair's first unit
-  EPI   N: no epilogue in the stream; R: ReLU + fp16 split of the previous pair; C: fp16 split only (signed values)
-  PAR   0: the pair accumulates in set E = v[240:247], the previous pair's results / next bias use O = v[248:255];
+  PAR   0: the pair accumulates in set E = v[240:247], the next pair's bias goes to O = v[248:255];
         1: the other way round.  Tile 0 (features 0-15 of the pair) is the low half of a set, tile 1 the high half.
 Operands (named):
   b<k>h / b<k>l   B operand (activations, high / low 16-bit parts) of k-step k                     [v, 128 bit, in]
   E0 E1 O0 O1     the four pinned accumulator tiles ("+{v[240:243]}" ...): on entry the current set holds the
-                  pair's bias, the other set the previous pair's finished accumulators (EPI R / C); on exit the
-                  current set holds this pair's results and the other set the next pair's bias      [pinned, in/out]
+                  pair's bias; on exit it holds this pair's main sums and the other set the next pair's bias
+                                                                                                    [pinned, in/out]
+  C0 C1           the pinned correction tiles ("=&{v[232:235]}", "=&{v[236:239]}"): written from zero (first MFMA of
+                  each takes the inline constant 0 as its C operand), hold the correction sums on exit [pinned, out]
   s0h..s2l        three A-operand register sets; on entry set 0 / 1 hold units 0 / 1 (landed), on exit set
                   (NU % 3) / ((NU+1) % 3) hold units NU / NU+1 (landed)                             [v, 128 bit, in/out]
   a0..a3          LDS byte address (ring slot base + 16*lane) of the phases the block touches      [v, 32 bit, in]
@@ -33,14 +37,10 @@ Operands (named):
   mv<e>, gb<e>    M0 value and 64-bit global base of the e-th phase opening inside the block       [s, in]
   voff            this lane's byte offset inside its wave's share of a phase (LDS-DMA vaddr)       [v, in]
   keep            scratch SGPR for M0                                                               [s, out&]
-  oh0..oh3, ol0..ol3   the previous pair's activations as fp16 high / low dwords (EPI R / C)       [v, 32 bit, out&]
-  fmax            running packed max of |high part| bit patterns (range guard)                      [v, in/out]
-  tmp             scratch VGPR (EPI C)                                                              [v, out&]
 
 Hazards handled in the text (hipcc pads nothing inside asm): >= 11 wait states after the last MFMA before the block
 ends (XDL 8-pass result -> VALU read), all ds_reads landed at the end (s_waitcnt lgkmcnt(0)), an A set / the other
-accumulator set is only overwritten by a ds_read issued after the last instruction reading it, the epilogue starts
-after the block's third MFMA (the previous block's last MFMA result is long complete).
+accumulator set is only overwritten by a ds_read issued after the last instruction reading it.
 """
 import os
 import sys
@@ -48,63 +48,32 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ABL = os.environ.get("FSN_KLOOP_ABL", "")
 WAIT2 = os.environ.get("FSN_KLOOP_WAIT2", "1") == "1"
-ILV = os.environ.get("FSN_KLOOP_ILV", "0") == "1"
-SPREAD = os.environ.get("FSN_KLOOP_SPREAD", "0") == "1"
 UPP = 8        # units per 16-KiB phase (a unit = 1 KiB high + 1 KiB low parts)
 UB = 2048      # bytes per unit in the x3 stream layout
 D = int(os.environ.get("FSN_KLOOP_D", "2"))   # units of A operands in flight ahead of the MFMAs (D + 1 register sets)
 LEAD = D       # a phase is opened LEAD units before the previous one ends
 LOADS = 4     # LDS-DMA loads (1 KiB each) of a loader wave per phase: four loader waves x 4 KiB
-NSETS = 4 if (os.environ.get("FSN_KLOOP_ILV", "0") == "1") else int(os.environ.get("FSN_KLOOP_D", "2")) + 1  # A register sets
+NSETS = D + 1  # A register sets
 SETS = {0: (240, 248), 1: (248, 240)}  # parity -> (first register of the current set, of the other set)
+CSET = 232     # first register of the correction set
 
 
 def tile(base, t):
     return f"v[{base + 4 * t}:{base + 4 * t + 3}]"
 
 
-def epilogue(kind, other):
-    """instructions of the previous pair's epilogue on the register set starting at `other`"""
-    if kind == "N":
-        return []
-    out = []
-    regs = [f"v{other + j}" for j in range(8)]
-    if kind == "R":
-        out += [f"v_max_i32 {r}, 0, {r}" for r in regs]
-    for i in range(4):
-        a, b = regs[2 * i], regs[2 * i + 1]
-        out.append(f"v_cvt_pk_f16_f32 %[oh{i}], {a}, {b}")
-        out.append(f"v_fma_mixlo_f16 %[ol{i}], %[oh{i}], -1.0, {a} op_sel_hi:[1,0,0]")
-        out.append(f"v_fma_mixhi_f16 %[ol{i}], %[oh{i}], -1.0, {b} op_sel:[1,0,0] op_sel_hi:[1,0,0]")
-        if kind == "C":
-            out.append(f"v_and_b32 %[tmp], 0x7fff7fff, %[oh{i}]")
-            out.append("v_pk_max_u16 %[fmax], %[fmax], %[tmp]")
-        else:
-            out.append(f"v_pk_max_u16 %[fmax], %[fmax], %[oh{i}]")
-    return out
-
-
-def block(mode, nu, off, kind, par):
+def block(mode, nu, off, par):
     cur, other = SETS[par]
     ins = []
     ev = 0
-    fill = [(t, False) for t in epilogue(kind, other)]
-    # next pair's bias into the other set, after the epilogue has consumed it
-    fill += [(f"ds_read_b128 {tile(other, 0)}, %[abn]", True), (f"ds_read_b128 {tile(other, 1)}, %[abn] offset:64", True)]
-    state = {"n_mfma": 0, "n_lds": 0, "dma_every": 3, "dma_wait": 0}
-    pend = []   # (FSN_KLOOP_SPREAD) instruction groups of the current stage still to be issued
-    # fillers per unit (three MFMAs): issue-slot budget of a SIMD shared by its two waves is ~24 slots per unit
-    # pair, of which the MFMAs, A reads and waits of both waves take 18 (measured: three fillers per unit cost
-    # ~20 cycles each, see DESIGN.md); FSN_KLOOP_FILL overrides for experiments
-    per_unit = int(os.environ.get("FSN_KLOOP_FILL", "0"))
-    # FSN_KLOOP_FILL = 0 (default): the previous pair's epilogue runs as ONE burst in front of unit BURST_AT, i.e. in
-    # the middle of the interval between the block's two phase openings.  Only waves 4..7 use the R / C variants:
-    # their SIMD partners (waves 0..3) run their epilogue at the end of the pair, so the two bursts of a SIMD are
-    # half a pair apart and each falls beside the partner's MFMAs.
-    burst_at = min(10, nu - 2) if per_unit == 0 else -1
-    if nu <= 4:
-        per_unit, burst_at = 8, -1   # the 12-MFMA pairs of the first layer: interleaved
+    # next pair's bias into the other set (its previous contents were consumed by the C++ epilogue before this block)
+    fill = [f"ds_read_b128 {tile(other, 0)}, %[abn]", f"ds_read_b128 {tile(other, 1)}, %[abn] offset:64"]
+    state = {"n_mfma": 0, "n_lds": 0}
+    # the two bias reads follow the MFMAs of unit FILL_AT (the middle of the interval between the block's two phase
+    # openings), one behind each; the 12-MFMA pairs of the first layer take them from their third MFMA on
+    fill_at = min(10, nu - 2) if nu > 4 else 0
     unit_last_read = {i: 0 for i in range(D)}    # number of ds_reads issued when the unit's last read was issued (0: landed on entry)
+    c_started = [False, False]                   # correction tile t has been written in this block
 
     def emit(text, lds=False):
         ins.append(text)
@@ -120,53 +89,31 @@ def block(mode, nu, off, kind, par):
             emit(f"ds_read_b128 %[s{s}l], %[a{ph}] offset:{o + 1024}", True)
         unit_last_read[u] = state["n_lds"]
 
-    def mfma(t, s, bop, n_fill):
-        n_fill = n_fill if per_unit else 0
-        c = tile(cur, t)
-        emit(f"MFMA {c}, %[s{s}], %[b{bop}], {c}")
+    def mfma(dst, src_c, s, bop, may_fill):
+        emit(f"MFMA {dst}, %[s{s}], %[b{bop}], {src_c}")
         state["n_mfma"] += 1
-        if pend:
-            state["dma_wait"] -= 1
-            if state["dma_wait"] <= 0:
-                for t in pend.pop(0):
-                    ins.append(t)
-                state["dma_wait"] = state["dma_every"]
-        if state["n_mfma"] >= 3:
-            for _ in range(n_fill):
-                if fill:
-                    text, is_lds = fill.pop(0)
-                    emit(text, is_lds)
+        if may_fill and fill and state["n_mfma"] >= 3:
+            emit(fill.pop(0), True)
 
-    npu = 3 if mode == "X3" else 2   # MFMAs per unit
-    share = [per_unit // npu + (1 if i < per_unit % npu else 0) for i in range(npu)]  # fillers behind each MFMA
+    def corr(t, s, bop, may_fill):
+        if "samechain" in ABL:   # timing experiment: the corrections into the main tile (rounds 1-2's dependency chain)
+            mfma(tile(cur, t), tile(cur, t), s, bop, may_fill)
+            return
+        c = tile(CSET, t)
+        mfma(c, c if c_started[t] else "0", s, bop, may_fill)
+        c_started[t] = True
 
     for u in range(nu):
         if (off + u + LEAD) % UPP == 0:
-            # open the next phase: its loads (all but the 2 youngest of this wave) have landed, every wave is past
-            # the phase whose slot is restaged; then issue this wave's two 1-KiB LDS-DMA loads of the phase after
-            # (FSN_KLOOP_ABL: timing experiments that drop parts of this - results are then garbage)
+            # open the next phase: its loads (all but the youngest LOADS of this wave) have landed, every wave is past
+            # the phase whose slot is restaged; then the loader waves issue their four 1-KiB LDS-DMA loads of the phase
+            # after (FSN_KLOOP_ABL: timing experiments that drop parts of this - results are then garbage)
             if "nobarrier" not in ABL:
                 ins += [f"s_waitcnt vmcnt({LOADS})", "s_barrier"]
-            if "nodma" not in ABL and SPREAD:
-                # FSN_KLOOP_SPREAD: the four loads of a loader wave are issued one at a time behind the following
-                # MFMAs instead of back to back behind the barrier (tools/ubench/gen_issue.py: a burst of four costs
-                # a w8 stream 11 points of matrix-pipe time, spread loads 3).  SCC holds "not a loader wave" and M0
-                # the stage's LDS base until the last of them (nothing else in a block writes either).
-                ins += ["v_readfirstlane_b32 %[keep], %[voff]", f"s_cmp_ge_u32 %[keep], {LOADS * 1024 * 4}",
-                        "s_mov_b32 %[keep], m0", f"s_mov_b32 m0, %[mv{ev}]"]
-                left = (nu - u) * (3 if mode == "X3" else 2)   # MFMAs from here to the end of the block
-                state["dma_every"] = max(1, min(3 if mode == "X3" else 2, left // (LOADS + 1)))
-                state["dma_wait"] = state["dma_every"]
-                for i in range(LOADS):
-                    pend.append([f"s_cbranch_scc1 .Lnl{ev}_{i}_%=",
-                                 f"global_load_lds_dwordx4 %[voff], %[gb{ev}]" + (f" offset:{1024 * i}" if i else ""),
-                                 f".Lnl{ev}_{i}_%=:"])
-                pend.append(["s_mov_b32 m0, %[keep]"])
-            elif "nodma" not in ABL:
-                # only the loader waves (0..3, %[ldr] != 0) issue LDS-DMA: the stall of issuing them then falls
-                # beside the MFMAs of their SIMD partners (waves 4..7) instead of on both waves at once
-                # (the predicate is taken from voff = 4096*wave + 16*lane: an "s" input operand may silently arrive in
-                # a VGPR, an "=&s" output cannot)
+            if "nodma" not in ABL:
+                # only the loader waves (voff < 4 x 4096) issue LDS-DMA: the stall of issuing them then falls beside
+                # the MFMAs of their SIMD partners instead of on both waves at once (the predicate is taken from
+                # voff = 4096*wave + 16*lane: an "s" input operand may silently arrive in a VGPR, an "=&s" output cannot)
                 ins += ["v_readfirstlane_b32 %[keep], %[voff]", f"s_cmp_ge_u32 %[keep], {LOADS * 1024 * 4}",
                         f"s_cbranch_scc1 .Lnoload{ev}_%=",
                         "s_mov_b32 %[keep], m0", f"s_mov_b32 m0, %[mv{ev}]", "s_nop 0"]
@@ -174,51 +121,25 @@ def block(mode, nu, off, kind, par):
                         for i in range(LOADS)]
                 ins += ["s_mov_b32 m0, %[keep]", f".Lnoload{ev}_%=:"]
             ev += 1
-        if u == burst_at:
-            bias = [f for f in fill if f[1]]
-            for text, is_lds in [f for f in fill if not f[1]]:
-                emit(text, False)
-            fill[:] = bias           # (the two bias reads follow behind the next MFMAs)
-            per_unit = 3
-            share = [1, 1, 1] if mode == "X3" else [2, 1]
-        if ILV and D == 2:
-            if u % 2 == 0:   # both units of the next k-step, into the two sets the previous k-step has released
-                read(u + 2)
-                read(u + 3)
-        else:
-            read(u + D)
+        read(u + D)
         # Every read of the units about to be used must have landed; LDS returns in order, so allow the reads issued
         # after their last one.  WAIT2 (default): one wait per k-step, in front of its first unit, covering both
         # of its units (one instruction less per k-step; the second unit's reads were issued a k-step ago).
-        if ILV and D == 2:
-            if u % 2 == 0:
-                ins.append(f"s_waitcnt lgkmcnt({state['n_lds'] - max(unit_last_read[u], unit_last_read.get(u + 1, 0))})")
-        elif WAIT2 and D == 2 and mode == "X3":  # (x2: measured 1.5 % slower with the merged wait)
+        if WAIT2 and D == 2 and mode == "X3":  # (x2: measured 1.5 % slower with the merged wait)
             if u % 2 == 0:
                 last = max(unit_last_read[u], unit_last_read.get(u + 1, 0))
                 ins.append(f"s_waitcnt lgkmcnt({state['n_lds'] - last})")
         else:
             ins.append(f"s_waitcnt lgkmcnt({state['n_lds'] - unit_last_read[u]})")
         k, t, s = u // 2, u % 2, u % NSETS
-        if ILV and D == 2:
-            # the two units of a k-step interleaved MFMA by MFMA: consecutive MFMAs never share an accumulator
-            if t == 0:
-                continue
-            s0 = (u - 1) % NSETS
-            mfma(0, f"{s0}h", f"{k}h", share[0]); mfma(1, f"{s}h", f"{k}h", 0)
-            if mode == "X3":
-                mfma(0, f"{s0}l", f"{k}h", share[1]); mfma(1, f"{s}l", f"{k}h", 0)
-            mfma(0, f"{s0}h", f"{k}l", share[-1]); mfma(1, f"{s}h", f"{k}l", 0)
-            continue
-        mfma(t, f"{s}h", f"{k}h", share[0])
+        may = u >= fill_at
+        c = tile(cur, t)
+        mfma(c, c, f"{s}h", f"{k}h", may)          # main sum: high x high
         if mode == "X3":
-            mfma(t, f"{s}l", f"{k}h", share[1])
-        mfma(t, f"{s}h", f"{k}l", share[-1])
-    for grp in pend:            # (a stage opened close to the end of the block)
-        ins.extend(grp)
-    pend.clear()
-    for text, is_lds in fill:   # (short pairs: what did not fit beside the MFMAs)
-        emit(text, is_lds)
+            corr(t, f"{s}l", f"{k}h", may)         # corrections (both scaled by 2^11 in the fp16 modes)
+        corr(t, f"{s}h", f"{k}l", may)
+    for text in fill:   # (never: every shape has room for the two bias reads)
+        emit(text, True)
     ins += ["s_waitcnt lgkmcnt(0)", "s_nop 7", "s_nop 3"]
     return ins, ev
 
@@ -227,9 +148,9 @@ def n_phases(nu, off):
     return (off + nu + D - 1) // UPP + 1
 
 
-def emit_macro(mode, nu, off, kind, par):
-    ins, ev = block(mode, nu, off, kind, par)
-    name = f"FSN_KLOOP_{mode}_{nu}_{off}_{kind}{par}"
+def emit_macro(mode, nu, off, par):
+    ins, ev = block(mode, nu, off, par)
+    name = f"FSN_KLOOP_{mode}_{nu}_{off}_N{par}"
     lines = [f"// {name}: {nu} units from unit {off} of a phase; {ev} phase opening(s); {n_phases(nu, off)} phase "
              f"address(es); {len(ins)} instructions", f"#define {name}(MFMA) \\"]
     for i in ins:
@@ -249,7 +170,7 @@ def main():
            "// Hand-scheduled GEMM-pair instruction streams for gfx950; see the generator's docstring.",
            "#pragma once", ""]
     for nu, off in SHAPES:
-        _, ev = block("X3", nu, off, "N", 0)
+        _, ev = block("X3", nu, off, 0)
         out.append(f"#define FSN_KLOOP_{nu}_{off}_EVENTS {ev}")
         out.append(f"#define FSN_KLOOP_{nu}_{off}_PHASES {n_phases(nu, off)}")
     out.append(f"#define FSN_KLOOP_D {D}")
@@ -257,9 +178,8 @@ def main():
     out.append("")
     for mode in ("X3", "X2"):
         for nu, off in SHAPES:
-            for kind in "NRC":
-                for par in (0, 1):
-                    out.append(emit_macro(mode, nu, off, kind, par))
+            for par in (0, 1):
+                out.append(emit_macro(mode, nu, off, par))
     dst = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "fs-nerf_amd", "csrc", "kloop_gen.hpp")
     open(dst, "w").write("\n".join(out))
     print("wrote", dst)
