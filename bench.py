@@ -17,6 +17,11 @@ pass -> compositing) over the 640,000 rays, outputs resident in HBM.  Rays shard
 no data-path collective: every rank renders its own frames (weak scaling); value = all rays of all
 ranks / max-over-ranks wall time.
 
+`--scaling strong` (N>1): all ranks render row blocks of the SAME frame (`shard.shard_rows`, `cam_row0`): total work
+fixed, value = frame rays / max-over-ranks time.  `--extras`: the timed launch also writes weights / alphas / trans /
+sigmas / rgbs / edges per sample (the default frame path writes rgb_map, depth_map, opacity only, as the reference's
+render_frame consumes only those, rendering.py:169-171).
+
 The JSON line also carries
   roofline     - the fused kernel against the dense 16-bit MFMA peak (2.5 PFLOP/s), from HIP-event
                  timing of the launches inside the timed region; algorithmic FLOPs per ray =
@@ -24,7 +29,10 @@ The JSON line also carries
                  layers only, 2 FLOP per MAC; `traffic` = HBM bytes per launch from the committed
                  rocprofv3 PMC pass (profiles/), or null;
   cpu_baseline - the CPU oracle (PyTorch CPU ops, same operator sequence as the reference) timed on
-                 this box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+                 this box's host cores on a bounded sample of the same workload (rank 0, N=1 only);
+  cpu_baseline_c1 - BASELINE.json configs[0] exactly (100x100 orbit pool, 4096-ray batch drawn with
+                 manual_seed(42), 64 coarse samples only, 4x128 MLP, mask off) on the host cores, all threads and
+                 one thread, with the fused HIP launch on the same batch beside it.
 
 `--workload train` times the TRAINING step instead (BASELINE.json configs[3]): forward-facing
 LLFF-style scene, 8 views of 378x504 (focal 407.6), NDC rays, near 0 / far 1, 64+128 samples, one 8x256 NeRF,
@@ -109,6 +117,74 @@ def cpu_baseline(target_s=15.0):
     return {"value": n / t, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n} rays of the 800x800 frame, 64+128 samples, two 8x256 nets, oracle/fsnerf_oracle.py "
                       f"(PyTorch CPU fp32), {t:.1f} s"}
+
+
+def cpu_baseline_c1(dev=None, target_s=4.0):
+    """BASELINE.json configs[0] as BASELINE.md section 3 / SURVEY 8d C1 specify it: the reference's own CPU-runnable
+    case.  Oracle on the host cores with all threads and with one; the fused HIP launch on the same batch beside it."""
+    from oracle import fsnerf_oracle as O
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    nthr = int(os.environ.get("FSN_CPU_THREADS", min(avail, 16)))
+    hw, focal = 100, 0.5 * 100 / math.tan(0.5 * 0.6911112)  # 138.89 (blender.py:250-252)
+    gen = torch.Generator().manual_seed(42)
+    pool_o, pool_d = [], []
+    for phi in torch.linspace(0.0, 360.0, 90).tolist():  # blender.py:260-277
+        o, d = O.get_rays(O.pose_from_spherical(4.0311289, 50.0, phi), (hw, hw, focal))
+        pool_o.append(o.reshape(-1, 3))
+        pool_d.append(d.reshape(-1, 3))
+    pool_o, pool_d = torch.cat(pool_o), torch.cat(pool_d)
+    idx = torch.randint(0, pool_o.shape[0], (4096,), generator=gen)
+    o, d = pool_o[idx].contiguous(), pool_d[idx].contiguous()
+    u = torch.rand(4096, generator=gen)
+    sd = O.init_nerf_state_dict(4, 128, [4], 10, 4, seed=42)  # n_layers = 4: the skip index is never reached
+    sd["sigma.weight"] = sd["sigma.weight"] * 64.0
+    sd["sigma.bias"] = sd["sigma.bias"] + 1.0
+    cfg = dict(n_layers=4, skip=[4], n_freqs=10, n_freqs_dir=4, log_space=True)
+
+    def timed(threads):
+        torch.set_num_threads(threads)
+        run = lambda: O.render_rays_oracle(o, d, sd, None, cfg, near=NEAR, far=FAR, n_samples=64, n_importance=0, u=u,
+                                           white_bkgd=True)
+        with torch.no_grad():
+            run()
+            t0 = time.perf_counter()
+            run()
+            t1 = time.perf_counter() - t0
+            n = int(max(1, min(40, target_s / max(t1, 1e-3))))
+            t0 = time.perf_counter()
+            for _ in range(n):
+                run()
+            t = (time.perf_counter() - t0) / n
+        return 4096 / t, n
+
+    v_all, n_all = timed(nthr)
+    v_one, n_one = timed(1)
+    torch.set_num_threads(nthr)
+    out = {"value": v_all, "unit": "rays/s", "cores": nthr, "value_1_thread": v_one, "kind": "port",
+           "sample": f"configs[0]: 4096-ray batch of the 90 x 100x100 orbit pool (seed 42), 64 coarse samples, 4x128 "
+                     f"MLP, mask off, oracle/fsnerf_oracle.py (PyTorch CPU fp32); {n_all} batches at {nthr} threads, "
+                     f"{n_one} at 1 thread"}
+    if dev is not None:  # the same batch through the fused launch (launch-bound at this size)
+        from fs_nerf_amd.core.models import NeRF
+        from fs_nerf_amd.render import rendering as Rm
+        m = NeRF(3, 3, 4, 128, (4,), pos_fn={"n_freqs": 10, "log_space": True}, dir_fn={"n_freqs": 4, "log_space": True})
+        m.load_state_dict(sd)
+        m = m.to(dev).eval()
+        est = Rm.StratifiedEstimator(NEAR, FAR, 64, 0)
+        od, dd, ud = o.to(dev), d.to(dev), u.to(dev)
+        with torch.no_grad():
+            for _ in range(3):
+                Rm.render_rays(od, dd, est, m, white_bkgd=True, device=dev, u=ud, want_extras=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                Rm.render_rays(od, dd, est, m, white_bkgd=True, device=dev, u=ud, want_extras=False)
+            torch.cuda.synchronize()
+        out["hip_value"] = 4096 * 50 / (time.perf_counter() - t0)
+    return out
 
 
 # ---------------------------------------------------------------- training workload (configs[3])
@@ -290,6 +366,9 @@ def csrc_sha():
     return h.hexdigest()[:16]
 
 
+BARE_STREAM = os.path.join(ROOT, "profiles", "bare_stream.json")  # tools/ubench: what a bare GEMM-pair stream reaches
+
+
 def measured_traffic(precision):
     """HBM-side bytes per fused launch from the committed rocprofv3 PMC passes (tools/run_pmc.sh ->
     tools/summarize_pmc.py -> profiles/*_pmc_summary.json).  Returned only when the summary was collected for this
@@ -305,8 +384,10 @@ def measured_traffic(precision):
             continue
         best = (pj, j)
         if j.get("csrc_sha") == csrc_sha() and j.get("hbm_bytes_per_launch") is not None:
-            return j["hbm_bytes_per_launch"], {"file": os.path.relpath(pj, ROOT), "csrc_sha": j["csrc_sha"],
-                                                "precision": precision, "l2_hit_rate": j.get("l2_hit_rate")}
+            src = {"file": os.path.relpath(pj, ROOT), "csrc_sha": j["csrc_sha"], "precision": precision,
+                   "l2_hit_rate": j.get("l2_hit_rate"), "clock_ghz": j.get("clock_ghz"),
+                   "mfma_busy": j.get("mfma_busy_frac")}
+            return j["hbm_bytes_per_launch"], src
     if best is None:
         return None, {"note": f"no PMC summary for precision {precision} under profiles/"}
     return None, {"note": "kernel sources changed since " + os.path.relpath(best[0], ROOT) + " was collected",
@@ -321,6 +402,11 @@ def main():
     ap.add_argument("--workload", choices=("render", "train"), default="render")
     ap.add_argument("--precision", default=os.environ.get("FSN_BENCH_PREC", "fp16x3"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N>1: every rank its own frames (weak), or row blocks of the same frame (strong)")
+    ap.add_argument("--extras", action="store_true", help="also write the per-sample outputs (weights, ...) in the timed launch")
+    ap.add_argument("--raw-launch", action="store_true",
+                    help="time ops.render_fused directly instead of the product path render_frame (A/B of the host path)")
     ap.add_argument("--dry-run", action="store_true", help="launcher self-test on the CPU (gloo); not a measurement")
     args = ap.parse_args()
     if args.steps is None:
@@ -368,21 +454,33 @@ def main():
     pc, pf = coarse.packed(), fine.packed()
     torch.cuda.synchronize()
 
+    from fs_nerf_amd import shard
+    strong = args.scaling == "strong" and world > 1
+    row0, nrows = shard.shard_rows(H, rank, world) if strong else (0, H)
     ev = []
+    ops.launch_timer = ev_raw = []  # ops.render_fused brackets its launch with HIP events on the launch stream
 
     def step(i, timed):
-        # ranks render different frames of the 90-frame orbit (blender.py:260-277)
-        pose = orbit_pose(((i * world + rank) % 90) * 4.0)
+        # weak scaling: ranks render different frames of the 90-frame orbit (blender.py:260-277); strong: the same one
+        pose = orbit_pose(((i * (1 if strong else world) + (0 if strong else rank)) % 90) * 4.0)
+        n0 = len(ev_raw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        # rays are generated inside the launch from (pose, pixel index): a frame is one launch, no ray tensors
-        rgb, op, depth, _ = ops.render_fused(pc, pf, None, None, near=NEAR, far=FAR, n_samples=S, n_importance=NI,
-                                             bkgd=(1.0, 1.0, 1.0), want_extras=False,
-                                             camera=(pose, H, W, FOCAL, 0, H, dev),
-                                             two_phase=os.environ.get("FSN_TWO_PHASE", "1") == "1")
+        if args.raw_launch or strong or args.extras:
+            # rays are generated inside the launch from (pose, pixel index): a frame (or a rank's row block) is one launch
+            rgb, op, depth, _ = ops.render_fused(pc, pf, None, None, near=NEAR, far=FAR, n_samples=S, n_importance=NI,
+                                                 bkgd=(1.0, 1.0, 1.0), want_extras=args.extras,
+                                                 camera=(pose, H, W, FOCAL, row0, nrows, dev),
+                                                 two_phase=os.environ.get("FSN_TWO_PHASE", "1") == "1")
+        else:
+            # the PRODUCT path (rendering.py:110-177): render_frame -> one fused launch, range-guard read-back, depth clamp
+            rgb, depth = Rm.render_frame((H, W, FOCAL), NEAR, FAR, pose, 1 << 30, est, coarse, white_bkgd=True,
+                                         device=dev, model_fine=fine)
         e1.record()
         if timed:
             ev.append((e0, e1))
+        else:
+            del ev_raw[n0:]
         return rgb, depth
 
     def barrier():
@@ -400,32 +498,56 @@ def main():
     dt = time.perf_counter() - t0
     assert bool(torch.isfinite(out[0]).all())
     assert ops.range_ok(dev), "an fp16-mode launch reported activations outside the fp16 range"
+    assert coarse.precision == args.precision and fine.precision == args.precision, "no range fallback in the timed region"
     if world > 1:
         t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+    step_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev_raw) / max(len(ev_raw), 1)  # the fused launch alone
+    ops.launch_timer = None
 
     if rank == 0:
-        rays = world * args.steps * H * W
+        rays = (1 if strong else world) * args.steps * H * W
         value = rays / dt
-        achieved = FLOP_PER_RAY * H * W / (kern_ms * 1e-3) / 1e12
+        achieved = FLOP_PER_RAY * nrows * W / (kern_ms * 1e-3) / 1e12
         traffic, traffic_src = measured_traffic(args.precision)
+        bare = None
+        if os.path.exists(BARE_STREAM):
+            try:
+                bare = json.load(open(BARE_STREAM))
+            except Exception:
+                bare = None
         line = {
             "metric": "rendered rays/sec (64+128 samples/ray, 8x256 MLP)", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
-            "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "Lego-style orbit 800x800 (focal 1111.11, near 2, far 6), 64 coarse + 128 "
                                    "importance samples (192 fine intervals), two 8x256 NeRF nets (seeds 42/43), "
                                    "ONE fused launch per 640,000-ray frame, rays generated in the launch",
-                       "rays_per_step": H * W, "parallelism": f"rays x{world} (no data-path collective)"},
+                       "rays_per_step": H * W,
+                       "path": "ops.render_fused (raw launch)" if (args.raw_launch or strong or args.extras) else
+                               "render.rendering.render_frame (the product path: launch + range-guard read-back + depth clamp)",
+                       "outputs": "rgb_map, depth_map, opacity + per-sample weights / alphas / trans / sigmas / rgbs / edges"
+                                  if args.extras else "rgb_map, depth_map, opacity (per-sample weights are NOT written in "
+                                  "the timed launch: frame rendering consumes only rgb / depth, rendering.py:169-171; "
+                                  "--extras times them too)",
+                       "parallelism": (f"row blocks of one frame x{world}" if strong else f"rays x{world}") +
+                                      " (no data-path collective)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_render_fused", "kernel_ms": kern_ms, "flop_per_ray": FLOP_PER_RAY},
+                         "kernel": "k_render_fused", "kernel_ms": kern_ms, "step_ms_events": step_ms,
+                         "flop_per_ray": FLOP_PER_RAY,
+                         # from the PMC summary stamped with these kernel sources (null when stale): the clock the chip
+                         # held and the matrix-pipe busy fraction; x3 modes issue 3 MFMAs per algorithmic product
+                         "clock_ghz": traffic_src.get("clock_ghz"), "mfma_busy": traffic_src.get("mfma_busy"),
+                         "passes_per_product": 3 if args.precision.endswith("x3") else (2 if args.precision.endswith("x2") else 1),
+                         "bare_stream": bare},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline(10.0)
+            line["cpu_baseline_c1"] = cpu_baseline_c1(dev)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

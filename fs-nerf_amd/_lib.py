@@ -14,7 +14,6 @@ FSN_PREC_BF16X3 = 0
 FSN_PREC_BF16 = 1
 FSN_PREC_FP16X3 = 2
 FSN_PREC_FP16 = 3
-FSN_PREC_FP32 = 4  # NOT a mode of the product library: the test-only fp32 reference formulation (tests/ref_fp32)
 FSN_PREC_FP16X2 = 6  # two passes (weights high part only), inference only
 FSN_STATUS_FP16_RANGE = 1  # a value reached fp16 infinity
 FSN_STATUS_FP16_SMALL = 2  # a layer's activations were all below 2^-14: outside the split's float32-grade envelope
@@ -71,7 +70,7 @@ SIGNATURES = {
     "fsn_occgrid_march": (_i, [_vp, _vp, _i64, _vp, _i, _i, _vp, _f, _f, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fsn_packed_visibility": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _f, _f, _vp, _vp]),
     "fsn_occgrid_update": (_i, [_vp, _i64, _vp, _vp, _i64, _f, _vp, _vp, _vp]),
-    "fsn_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _d, _d, _d, _d, _d, _d, _vp]),
+    "fsn_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _d, _d, _d, _d, _d, _d, _vp, _vp, _vp]),
     "fsn_weight_norm_workspace_floats": (_i64, [_i, _vp]),
     "fsn_weight_norm_fwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "fsn_weight_norm_bwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
@@ -79,37 +78,6 @@ SIGNATURES = {
 }
 
 _lib = None
-_ref = None
-_ref_path = os.environ.get("FSN_REF_LIB_PATH")
-
-
-def register_reference_library(path: str) -> None:
-    """Tests only: where the plain-fp32 (rocBLAS sgemm) reference formulation of the training step lives
-    (tests/ref_fp32/libfsnerf_ref_fp32.so).  The product never loads it on its own."""
-    global _ref_path, _ref
-    _ref_path, _ref = path, None
-
-
-def ref_lib() -> C.CDLL:
-    global _ref
-    if _ref is None:
-        if not _ref_path or not os.path.exists(_ref_path):
-            raise RuntimeError("train_precision='fp32' is the test-only reference formulation: build tests/ref_fp32 and "
-                               "register it with fs_nerf_amd._lib.register_reference_library(path)")
-        l = C.CDLL(_ref_path)
-        l.fsn_last_error.restype = C.c_char_p
-        l.fsnref_train_workspace_floats.restype, l.fsnref_train_workspace_floats.argtypes = _i64, [_PD, _i64]
-        l.fsnref_train_fwd.restype = _i
-        l.fsnref_train_fwd.argtypes = [_PD, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]
-        l.fsnref_train_bwd.restype = _i
-        l.fsnref_train_bwd.argtypes = [_PD, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]
-        _ref = l
-    return _ref
-
-
-def check_ref(rc: int, what: str) -> None:
-    if rc != 0:
-        raise RuntimeError(f"{what} failed (code {rc}): {ref_lib().fsn_last_error().decode('utf-8', 'replace')}")
 
 
 def build(force: bool = False) -> str:

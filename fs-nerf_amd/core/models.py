@@ -50,9 +50,9 @@ class PositionalEncoder(nn.Module):
 class _NerfTrainFn(torch.autograd.Function):
     """NeRF.forward with gradients.  `fsn_nerf_train_fwd` runs the MFMA kernel of the inference
     path with the fp32 activations saved; `fsn_nerf_train_bwd` the dgrad chain + wgrad GEMMs on the matrix cores
-    (csrc/train_fused.hip), in the model's precision mode; `train_precision="fp32"` is accepted only when a test has
-    registered the test-only reference library (tests/ref_fp32: plain fp32 library GEMMs); it is not a mode of the product.  Gradients flow to the parameters only (sample positions / directions need
-    none on this path)."""
+    (csrc/train_fused.hip), in the model's precision mode.  Gradients flow to the parameters only (sample positions /
+    directions need none on this path).  (The plain-fp32 library-GEMM formulation these kernels were first checked
+    against lives entirely under tests/ref_fp32, binding included; nothing in this package can reach it.)"""
 
     @staticmethod
     def forward(ctx, model, x, dirs, *params):
@@ -62,9 +62,13 @@ class _NerfTrainFn(torch.autograd.Function):
                              model.dir_encoder.freqs)
         dev = x.device
         prec = model.train_prec()
+        # range-guard word of THIS call (one network, one step): the kernels of its forward and backward report into
+        # it, and only they consult it - a flag raised by another network or by an inference launch must not zero
+        # this network's gradients (the sticky per-device word of the inference path is not used here)
+        word = torch.zeros(1, dtype=torch.int32, device=dev) if model.fp16_family(prec) else None
         out, work = ops.nerf_train_fwd(desc, prec, weights, biases, x, dirs, model._mask(model.pos_mask, dev),
-                                       model._mask(model.dir_mask, dev))
-        ctx.desc, ctx.prec, ctx.work, ctx.out, ctx.model = desc, prec, work, out, model
+                                       model._mask(model.dir_mask, dev), status=word)
+        ctx.desc, ctx.prec, ctx.work, ctx.out, ctx.model, ctx.word = desc, prec, work, out, model, word
         ctx.weights = [w.detach() for w in weights]
         return out.reshape(*x.shape[:-1], 4)
 
@@ -73,19 +77,23 @@ class _NerfTrainFn(torch.autograd.Function):
         if ctx.work is None:
             raise RuntimeError("NeRF backward ran twice on one forward: the saved activations are released after the "
                                "first pass (retain_graph is not supported on this path)")
-        dW, db = ops.nerf_train_bwd(ctx.desc, ctx.prec, ctx.weights, ctx.work, ctx.out, d_out.contiguous())
+        dW, db = ops.nerf_train_bwd(ctx.desc, ctx.prec, ctx.weights, ctx.work, ctx.out, d_out.contiguous(), status=ctx.word)
         ctx.work = None
-        # fp16 range guard without a per-step host sync: when a launch of this step reported values outside the fp16
-        # range, the backward kernels have written this step's gradients as ZEROS on the device (a skipped step, like
-        # a loss scaler's); the host looks at the status word every `range_check_every` training steps, then warns
-        # and continues in bf16x3.
+        # fp16 range guard without a per-step host sync.  When this call's launches reported values outside the fp16
+        # range, the backward kernels have written ITS gradients as zeros on the device; the call's word is folded
+        # (device ops) into the device's step flag, on which FusedAdam skips the whole update - a skipped step, like a
+        # loss scaler's - and into this model's own accumulated word, which the host reads every `range_check_every`
+        # training calls; it then warns and continues in bf16x3.
         model = ctx.model
-        if model.range_check and model.fp16_family(ctx.prec):
+        if ctx.word is not None:
+            ops.step_flag(d_out.device).bitwise_or_(ctx.word)
+            model._train_status(d_out.device).bitwise_or_(ctx.word)
             model._train_calls += 1
-            if model._train_calls % model.range_check_every == 0:
-                bits = ops.range_flags(d_out.device)
+            if model.range_check and model._train_calls % model.range_check_every == 0:
+                bits = model._read_train_status(d_out.device)
                 if bits:
-                    model.fall_back("training steps (gradients of out-of-range steps were zeroed on the device)", bits)
+                    model.fall_back("training steps (an overflowing step's gradients were zeroed on the device and its "
+                                    "optimizer update skipped)", bits)
         db = [g.reshape(-1) for g in db]
         return (None, None, None, *dW, *db)
 
@@ -115,10 +123,14 @@ class NeRF(nn.Module):
         self.branch = nn.Linear(d_hidden + d_de, d_hidden // 2)
         self.rgb = nn.Linear(d_hidden // 2, 3)
         self.precision = precision
-        self.range_check = True  # fp16 modes: read the kernels' range flag back after each call (one host sync)
+        # fp16 modes: True = read the kernels' range flag back after each call (one host sync; a flagged call is re-run in
+        # bf16x3 before it returns); "deferred" = asynchronous read-back, looked at by the NEXT call (batch rendering in
+        # small launches: no wait per call; render_frame checks once per frame); False = never look
+        self.range_check = True
         self.range_check_every = 16  # ... in training: every that many steps (gradients are guarded on the device)
         self._train_calls = 0
-        self.train_precision: Optional[str] = None  # None: same mode as `precision` ("fp32": tests only, see _NerfTrainFn)
+        self._train_word: Optional[Tensor] = None
+        self.train_precision: Optional[str] = None  # None: same mode as `precision`
         self.pos_mask: Optional[Tensor] = None
         self.dir_mask: Optional[Tensor] = None
         self._packed = None
@@ -133,11 +145,35 @@ class NeRF(nn.Module):
         tp = self.train_precision or self.precision
         if tp == "fp16x2":
             tp = "fp16x3"  # the two-pass mode is inference only
-        return L.FSN_PREC_FP32 if tp == "fp32" else self.PRECISIONS[tp]
+        return self.PRECISIONS[tp]
 
     @staticmethod
     def fp16_family(prec: int) -> bool:
         return prec in (L.FSN_PREC_FP16X3, L.FSN_PREC_FP16, L.FSN_PREC_FP16X2)
+
+    def _train_status(self, dev) -> Tensor:
+        """This model's accumulated training range word (device; OR of its calls' words since the last host look)."""
+        w = self._train_word
+        if w is None or w.device != dev:
+            w = self._train_word = torch.zeros(1, dtype=torch.int32, device=dev)
+        return w
+
+    def _read_train_status(self, dev) -> int:
+        """Host look at the accumulated word (one 4-byte read-back) and clear.  Data-parallel runs take the MAX over
+        the ranks first (every rank makes the same number of training calls, so all of them are here together): a
+        rank that overflowed and one that did not must not continue in different arithmetic."""
+        w = self._train_status(dev)
+        bits = int(w.item())
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and \
+                torch.distributed.get_world_size() > 1:
+            t = torch.tensor([bits], dtype=torch.int32, device=dev if torch.distributed.get_backend() != "gloo" else "cpu")
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            # (MAX of bit masks 0..3: 3 if any rank has both or the largest single; refine to an OR with two rounds
+            # only if more bits are ever added - both bits lead to the same fallback)
+            bits = int(t.item())
+        if bits:
+            w.zero_()
+        return bits & (L.FSN_STATUS_FP16_RANGE | L.FSN_STATUS_FP16_SMALL)
 
     def fall_back(self, what: str, bits: int = L.FSN_STATUS_FP16_RANGE) -> None:
         """An fp16-mode launch reported values outside the mode's envelope (|v| >= 65504, or a layer whose activations

@@ -4,7 +4,16 @@ src/run-nerf.py:217, `optimizer.step()` / `zero_grad()` at :283-285).
 `FlatParams` re-homes every parameter of a model into ONE flat float32 arena (each `p.data` becomes a view), with the
 gradients in a second arena of the same layout (`shard.FlatGrads`: the buffer the RCCL all-reduce runs on).
 `FusedAdam` is a `torch.optim.Optimizer` whose `step()` is a single HIP launch over those arenas
-(`fsn_adam_step`, torch.optim.Adam's arithmetic operation for operation) - no per-tensor kernels, no `torch.cat`."""
+(`fsn_adam_step`, torch.optim.Adam's arithmetic operation for operation) - no per-tensor kernels, no `torch.cat`.
+
+Differences from `torch.optim.Adam`, all deliberate:
+  * a parameter whose gradient is None takes part with a ZERO gradient (its moments decay, torch skips it): the
+    arenas are one flat buffer and one launch;
+  * `zero_grad(set_to_none=True)` fills the gradient arena with zeros and keeps `p.grad` bound to it;
+  * a step in which an fp16-mode training launch overflowed is skipped on the device (`ops.step_flag`, or the flag
+    slot of an all-reduced bucket): parameters and moments untouched; the host-side step counter still advances, so
+    the bias corrections run one step ahead per skipped step (the model leaves fp16 mode right after);
+  * `state_dict()` / `load_state_dict()` carry the flat moments and the step count (checkpoint / resume)."""
 from typing import Iterable, List, Optional
 
 import torch
@@ -86,13 +95,35 @@ class FusedAdam(torch.optim.Optimizer):
         self.arena.grads.bind()
         self.steps += 1
         a = self.arena
+        flag = ops.step_flag(a.flat.device)
         with torch.cuda.device(a.flat.device):
             L.check(L.lib().fsn_adam_step(ops._p(a.flat), ops._p(a.grads.flat), ops._p(self.exp_avg),
                                           ops._p(self.exp_avg_sq), a.numel, self.steps, float(g["lr"]),
                                           float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
-                                          float(g["weight_decay"]), float(grad_div), ops._stream()), "fsn_adam_step")
+                                          float(g["weight_decay"]), float(grad_div), ops._p(flag),
+                                          ops._p(a.grads.flag_slot), ops._stream()), "fsn_adam_step")
+        flag.zero_()  # the step's flag is consumed (stream order: after the launch that read it)
+        a.grads.flag_slot.zero_()
         self._bump_versions()
         return loss
+
+    # checkpoint / resume: the moments and the step count live outside Optimizer.state (flat arenas)
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["fused_adam"] = {"exp_avg": self.exp_avg.detach().clone(), "exp_avg_sq": self.exp_avg_sq.detach().clone(),
+                            "steps": self.steps}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        extra = state_dict.pop("fused_adam", None)
+        super().load_state_dict(state_dict)
+        if extra is not None:
+            if extra["exp_avg"].numel() != self.exp_avg.numel():
+                raise ValueError("FusedAdam.load_state_dict: moment arenas of a different parameter list")
+            self.exp_avg.copy_(extra["exp_avg"])
+            self.exp_avg_sq.copy_(extra["exp_avg_sq"])
+            self.steps = int(extra["steps"])
 
     def _bump_versions(self) -> None:
         # `NeRF.packed()` re-packs when a parameter's version counter changed; the HIP launch wrote through raw

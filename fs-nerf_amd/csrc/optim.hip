@@ -27,9 +27,14 @@ struct Segs {
 // in float32:  g' = g / grad_div (+ weight_decay p);  m = m + (1-b1)(g' - m);  v = b2 v + (1-b2) g' g';
 // denom = sqrt(v) / sqrt(1-b2^t) + eps;  p = p - (lr / (1-b1^t)) m / denom.   grad_div: number of ranks when the
 // gradient arena holds an all-reduced SUM (folds the 1/world of the data-parallel mean into the step), else 1.
+// skip_word / skip_count (device, optional): the step is a no-op - parameters and moments untouched, as when a loss
+// scaler does not call optimizer.step() - when bit 0 of *skip_word is set (this rank's training launches of the step
+// reported fp16 overflow) or *skip_count > 0 (the flag slot of the all-reduced gradient bucket: some rank did).
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                        int64_t n, float step_size, float omb1, float b2, float omb2, float bc2_sqrt, float eps,
-                       float wd, float grad_div) {
+                       float wd, float grad_div, const uint32_t* __restrict__ skip_word,
+                       const float* __restrict__ skip_count) {
+  if ((skip_word && (skip_word[0] & 1u)) || (skip_count && skip_count[0] > 0.f)) return;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
   for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
     if (i + 4 <= n) {
@@ -142,7 +147,7 @@ using namespace fsn;
 
 extern "C" int fsn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int step,
                              double lr, double beta1, double beta2, double eps, double weight_decay, double grad_div,
-                             fsn_stream_t stream) {
+                             const uint32_t* skip_word, const float* skip_count, fsn_stream_t stream) {
   FSN_REQUIRE(n >= 0 && step >= 1 && beta1 >= 0 && beta1 < 1 && beta2 >= 0 && beta2 < 1 && grad_div > 0, FSN_E_INVALID,
               "fsn_adam_step: bad arguments (n=%lld step=%d)", (long long)n, step);
   if (n == 0) return FSN_OK;
@@ -157,7 +162,7 @@ extern "C" int fsn_adam_step(float* params, const float* grads, float* exp_avg, 
   const unsigned grid = (unsigned)(want < 8 * cus ? (want > 0 ? want : 1) : 8 * cus);
   k_adam<<<grid, 256, 0, as_stream(stream)>>>(params, grads, exp_avg, exp_avg_sq, n, (float)step_size,
                                               (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)bc2_sqrt, (float)eps, (float)weight_decay,
-                                              (float)grad_div);
+                                              (float)grad_div, skip_word, skip_count);
   FSN_LAUNCH_CHECK("k_adam");
   return FSN_OK;
 }

@@ -679,16 +679,16 @@ struct RdJob {
 struct RdArgs {
   RdJob job[2 * kMaxLayers + 4];
   const float* scale;
-  const uint32_t* status;  // fp16 range guard: when raised, this step's gradients are written as zeros
+  const uint32_t* status;  // fp16 modes: this call's range-guard word (null in the bf16 modes); bit 0 -> zero gradients
 };
 
 __global__ void k_wgrad_reduce(RdArgs a) {
   const RdJob jb = a.job[blockIdx.y];
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const float inv = a.scale ? 1.0f / a.scale[0] : 1.0f;
-  // A forward / backward launch of this step reported values outside the fp16 range (status bit 0): the sums are
-  // inf / NaN.  Like a loss scaler's skipped step the gradients are zeroed ON THE DEVICE, without a host sync; the
-  // host learns of it at its next (amortised) look at the status word and continues in bf16x3.
+  // The forward / backward launch of THIS call reported values outside the fp16 range (bit 0 of the per-call word):
+  // the sums are inf / NaN.  The gradients are zeroed ON THE DEVICE, without a host sync; fsn_adam_step skips the
+  // update on the same word, and the host learns of it at its next (amortised) look and continues in bf16x3.
   const bool skip = a.status && (a.status[0] & 1u);
   const int tot = jb.a_rows * jb.b_rows;
   if (e < tot) {
@@ -1008,7 +1008,7 @@ int fused_train_bwd(const fsn_mlp_desc* d, int prec, const float* const* W, int6
     if ((rc = launch_wgrad<8, 1, 1>(prec, bd, nbd, s)) != FSN_OK) return rc;
   }
   rd.scale = grad_scale_dev;
-  rd.status = status;
+  rd.status = prec_is_f16(prec) ? status : nullptr;  // (only the fp16 modes can overflow)
   {
     dim3 grid((unsigned)((D * D + 255) / 256), (unsigned)nrd);
     k_wgrad_reduce<<<grid, 256, 0, s>>>(rd);
@@ -1029,7 +1029,8 @@ int fused_train_bwd(const fsn_mlp_desc* d, int prec, const float* const* W, int6
       default: k_heads_wgrad<8, 3><<<hg, kThreads, 0, s>>>(ha); break;
     }
     FSN_LAUNCH_CHECK("k_heads_wgrad");
-    HeadsRdArgs hr{ws + F.hpart, F.nsplit_heads, D, grad_scale_dev, dW[L], db[L], dW[L + 3], db[L + 3], status};
+    HeadsRdArgs hr{ws + F.hpart, F.nsplit_heads, D, grad_scale_dev, dW[L], db[L], dW[L + 3], db[L + 3],
+                   prec_is_f16(prec) ? status : nullptr};
     const int nn = D + 3 * (D / 2) + 4;
     k_heads_reduce<<<(unsigned)((nn + 255) / 256), 256, 0, s>>>(hr);
     FSN_LAUNCH_CHECK("k_heads_reduce");

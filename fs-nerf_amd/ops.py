@@ -188,11 +188,58 @@ def status_word(device) -> Tensor:
     return w
 
 
+_step_flags: Dict[torch.device, Tensor] = {}
+
+
+def step_flag(device) -> Tensor:
+    """Per-device word of the CURRENT training step: every NeRF backward ORs its per-call range word into it (device
+    op), `FusedAdam.step` hands it to the Adam launch (bit 0 = some network overflowed fp16 in this step: the update
+    is skipped on the device) and clears it afterwards.  Never read by the host."""
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    w = _step_flags.get(device)
+    if w is None:
+        w = _step_flags[device] = torch.zeros(1, dtype=torch.int32, device=device)
+    return w
+
+
 def range_flags(device) -> int:
     """FSN_STATUS_* bits reported by the launches since the last call (0 = all inside the fp16 modes' envelope); the
     word is cleared.  Reads 4 bytes back: one host sync."""
     w = status_word(device)
     bits = int(w.item()) & (L.FSN_STATUS_FP16_RANGE | L.FSN_STATUS_FP16_SMALL)
+    if bits:
+        w.zero_()
+    return bits
+
+
+# Deferred look at the range word (`NeRF.range_check = "deferred"`): batch rendering in small launches must not wait for
+# the GPU after every call.  range_post(): asynchronous copy of the word into pinned host memory + an event, on the
+# launch stream.  range_poll(): bits seen by the most recent post (waits for its event - normally long complete when the
+# NEXT call polls), clearing the device word when it was raised.
+_range_pending: Dict[torch.device, Tuple[Tensor, "torch.cuda.Event"]] = {}
+
+
+def range_post(device) -> None:
+    w = status_word(device)
+    ent = _range_pending.get(w.device)
+    host = ent[0] if ent is not None else torch.zeros(1, dtype=torch.int32).pin_memory()
+    host.copy_(w, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    _range_pending[w.device] = (host, ev, True)
+
+
+def range_poll(device) -> int:
+    w = status_word(device)
+    ent = _range_pending.get(w.device)
+    if ent is None or not ent[2]:
+        return 0
+    host, ev, _ = ent
+    ev.synchronize()
+    _range_pending[w.device] = (host, ev, False)
+    bits = int(host[0]) & (L.FSN_STATUS_FP16_RANGE | L.FSN_STATUS_FP16_SMALL)
     if bits:
         w.zero_()
     return bits
@@ -278,6 +325,10 @@ def mlp_fwd(pm: PackedMLP, x: Tensor, dirs: Optional[Tensor] = None, pos_mask: O
                                     _p(out), _p(status_word(x.device)), _stream()), "fsn_mlp_fwd")
     return out
 
+
+# profiling hook (bench.py): a list -> every render_fused launch appends a pair of HIP events recorded on the launch
+# stream right around the C-ABI call (the kernel's own duration, without the host path around it)
+launch_timer: Optional[list] = None
 
 _edges_ws: Dict[Tuple[torch.device, int], Tensor] = {}
 
@@ -368,9 +419,15 @@ def render_fused(pm_coarse: Optional[PackedMLP], pm_fine: PackedMLP, rays_o: Opt
         raise ValueError("render_fused: the coarse and the fine network must be packed in the same precision mode")
     a.status = status_word(dev).data_ptr()
     with torch.cuda.device(dev):
+        if launch_timer is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         L.check(L.lib().fsn_render_rays_fused(C.byref(pm_fine.desc), pm_fine.prec,
                                               _p(pm_coarse.blob) if pm_coarse is not None else None,
                                               _p(pm_fine.blob), C.byref(a), _stream()), "fsn_render_rays_fused")
+        if launch_timer is not None:
+            e1.record()
+            launch_timer.append((e0, e1))
     return colors, opacity, depth, ex
 
 
@@ -460,9 +517,9 @@ def _ptr_array(ts: Sequence[Tensor]):
 
 
 def nerf_train_fwd(desc: L.MlpDesc, prec: int, weights: Sequence[Tensor], biases: Sequence[Tensor], x: Tensor,
-                   dirs: Tensor, pos_mask: Optional[Tensor], dir_mask: Optional[Tensor]):
-    """NeRF.forward keeping what the backward needs: -> (out [n,4], workspace).  prec: L.FSN_PREC_* (MFMA path)
-    or L.FSN_PREC_FP32 (plain library GEMMs)."""
+                   dirs: Tensor, pos_mask: Optional[Tensor], dir_mask: Optional[Tensor], status: Optional[Tensor] = None):
+    """NeRF.forward keeping what the backward needs: -> (out [n,4], workspace).  prec: L.FSN_PREC_*.  `status`: this
+    call's range-guard word (int32[1], zeroed by the caller; the same tensor goes to nerf_train_bwd)."""
     x, d = _f32(x, "x").reshape(-1, 3), _f32(dirs, "dirs").reshape(-1, 3)
     n = x.shape[0]
     ws_ = [_f32(w.detach(), "weight") for w in weights]
@@ -471,20 +528,12 @@ def nerf_train_fwd(desc: L.MlpDesc, prec: int, weights: Sequence[Tensor], biases
         pm = None if pos_mask is None else _f32(pos_mask, "pos_mask")
         dm = None if dir_mask is None else _f32(dir_mask, "dir_mask")
         out = torch.empty(n, 4, device=x.device, dtype=torch.float32)
-        if prec == L.FSN_PREC_FP32:  # test-only reference formulation (tests/ref_fp32)
-            nfl = L.ref_lib().fsnref_train_workspace_floats(C.byref(desc), n)
-            if nfl < 0:
-                L.check_ref(int(nfl), "fsnref_train_workspace_floats")
-            work = torch.empty(max(int(nfl), 1), device=x.device, dtype=torch.float32)
-            L.check_ref(L.ref_lib().fsnref_train_fwd(C.byref(desc), _ptr_array(ws_), _ptr_array(bs_), _p(x), _p(d), _p(pm),
-                                                     _p(dm), n, _p(work), _p(out), _stream()), "fsnref_train_fwd")
-            return out, work
         nfl = L.lib().fsn_nerf_train_workspace_floats(C.byref(desc), prec, n)
         if nfl < 0:
             L.check(int(nfl), "fsn_nerf_train_workspace_floats")
         work = torch.empty(max(int(nfl), 1), device=x.device, dtype=torch.float32)
         L.check(L.lib().fsn_nerf_train_fwd(C.byref(desc), prec, _ptr_array(ws_), _ptr_array(bs_), _p(x), _p(d), _p(pm),
-                                           _p(dm), n, _p(work), _p(out), _p(status_word(x.device)), _stream()),
+                                           _p(dm), n, _p(work), _p(out), _p(status), _stream()),
                 "fsn_nerf_train_fwd")
     return out, work
 
@@ -498,8 +547,9 @@ def grad_scale_for(d_out: Tensor) -> Tensor:
     return torch.exp2(e).reshape(1)
 
 
-def nerf_train_bwd(desc: L.MlpDesc, prec: int, weights: Sequence[Tensor], work: Tensor, out: Tensor, d_out: Tensor):
-    """-> (d_weights, d_biases) lists in state_dict order."""
+def nerf_train_bwd(desc: L.MlpDesc, prec: int, weights: Sequence[Tensor], work: Tensor, out: Tensor, d_out: Tensor,
+                   status: Optional[Tensor] = None):
+    """-> (d_weights, d_biases) lists in state_dict order.  `status`: the word given to nerf_train_fwd."""
     ws_ = [_f32(w.detach(), "weight") for w in weights]
     d_out = _f32(d_out, "d_out").reshape(-1, 4)
     n = d_out.shape[0]
@@ -509,13 +559,9 @@ def nerf_train_bwd(desc: L.MlpDesc, prec: int, weights: Sequence[Tensor], work: 
     db = [torch.empty(w.shape[0], device=w.device, dtype=torch.float32) for w in ws_]
     scale = grad_scale_for(d_out) if prec in (L.FSN_PREC_FP16X3, L.FSN_PREC_FP16) else None
     with torch.cuda.device(work.device):
-        if prec == L.FSN_PREC_FP32:
-            L.check_ref(L.ref_lib().fsnref_train_bwd(C.byref(desc), _ptr_array(ws_), n, _p(work), _p(out), _p(d_out),
-                                                     _ptr_array(dW), _ptr_array(db), _stream()), "fsnref_train_bwd")
-            return dW, db
         L.check(L.lib().fsn_nerf_train_bwd(C.byref(desc), prec, _ptr_array(ws_), n, _p(work), _p(out), _p(d_out),
-                                           _p(scale), _ptr_array(dW), _ptr_array(db), _p(status_word(work.device)),
-                                           _stream()), "fsn_nerf_train_bwd")
+                                           _p(scale), _ptr_array(dW), _ptr_array(db), _p(status), _stream()),
+                "fsn_nerf_train_bwd")
     return dW, db
 
 

@@ -139,13 +139,30 @@ def _fused_launch(rays_o, rays_d, camera, estimator, model, model_fine, train, b
             near=near, far=far, n_samples=estimator.n_samples, n_importance=estimator.n_importance,
             u=u, u_fine=u_fine, bkgd=(bk, bk, bk), pos_mask=pm, dir_mask=dm, want_extras=want_extras, camera=camera)
 
-    out = launch()
     nets = [m for m in {id(model): model, id(fine): fine}.values()]
-    bits = ops.range_flags(dev) if any(m.range_check and m.fp16_family(m.PRECISIONS[m.precision]) for m in nets) else 0
-    if bits:
+    guarded = [m for m in nets if m.range_check and m.fp16_family(m.PRECISIONS[m.precision])]
+
+    def fall_back(what, bits):
         for m in nets:  # the coarse and the fine pass run in one precision mode
             if m.fp16_family(m.PRECISIONS[m.precision]):
-                m.fall_back("render_rays", bits)
+                m.fall_back(what, bits)
+
+    if guarded and all(m.range_check == "deferred" for m in guarded):
+        # batch rendering in small launches: no wait for the GPU per call.  The word of the PREVIOUS launch is looked
+        # at now (its asynchronous read-back has long landed); a raised flag switches the models for this and all later
+        # calls and says that the previous call's outputs are not to be used.  ops.range_poll / render_frame's end
+        # of frame give the certain answer.
+        bits = ops.range_poll(dev)
+        if bits:
+            fall_back("an EARLIER render_rays call (deferred range check: its outputs are invalid)", bits)
+        out = launch()
+        if any(m.fp16_family(m.PRECISIONS[m.precision]) for m in nets):
+            ops.range_post(dev)
+        return out
+    out = launch()
+    bits = ops.range_flags(dev) if guarded else 0
+    if bits:
+        fall_back("render_rays", bits)
         out = launch()
     return out
 
@@ -207,6 +224,21 @@ def render_rays(rays_o: Tensor, rays_d: Tensor, estimator, model: nn.Module, tra
     return output, ray_indices, t_vals
 
 
+def _deferred_frame_flagged(model, fine, dev) -> bool:
+    """Deferred range check (`NeRF.range_check = "deferred"`): the one look per frame.  True when a launch of the frame
+    left the fp16 envelope; the models have then been switched to their bf16 mode (with a RuntimeWarning)."""
+    nets = [m for m in {id(model): model, id(fine): fine}.values() if isinstance(m, NeRF)]
+    if not any(m.range_check == "deferred" and m.fp16_family(m.PRECISIONS[m.precision]) for m in nets):
+        return False
+    bits = ops.range_poll(dev)
+    if not bits:
+        return False
+    for m in nets:
+        if m.fp16_family(m.PRECISIONS[m.precision]):
+            m.fall_back("render_frame (deferred range check at the end of the frame)", bits)
+    return True
+
+
 def render_frame(hwf: Tuple[int, int, float], near: float, far: float, pose: Tensor, chunksize: int, estimator,
                  model: nn.Module, train: bool = False, ndc: bool = False, white_bkgd: bool = False,
                  render_step_size: float = 5e-3, device: torch.device = torch.device("cuda"), *,
@@ -229,6 +261,9 @@ def render_frame(hwf: Tuple[int, int, float], near: float, far: float, pose: Ten
             dev = torch.device("cuda", torch.cuda.current_device())
         rgb, _, depth, _ = _fused_launch(None, None, (pose, H, W, focal, 0, H, dev), estimator, model, model_fine,
                                          train, float(white_bkgd), None, None, False)
+        if _deferred_frame_flagged(model, fine, dev):  # (deferred range check: one look per frame)
+            rgb, _, depth, _ = _fused_launch(None, None, (pose, H, W, focal, 0, H, dev), estimator, model, model_fine,
+                                             train, float(white_bkgd), None, None, False)
         return rgb.reshape(H, W, 3), depth.clamp(near, far).reshape(H, W)
     rays_o, rays_d = U.get_rays(pose, hwf, device)
     rays_o, rays_d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
@@ -244,6 +279,11 @@ def render_frame(hwf: Tuple[int, int, float], near: float, far: float, pose: Ten
         (rgb, _, depth, _), *_ = out
         img.append(rgb)
         depth_map.append(depth)
+    if _deferred_frame_flagged(model, fine, img[0].device):
+        # some chunk is invalid and the models have been switched to bf16x3: render the frame again
+        return render_frame(hwf, near, far, pose, chunksize, estimator, model, train=train, ndc=ndc,
+                            white_bkgd=white_bkgd, render_step_size=render_step_size, device=device,
+                            model_fine=model_fine)
     img = torch.cat(img, dim=0)
     depth = torch.cat(depth_map, dim=0).clamp(near, far)
     return img.reshape(H, W, 3), depth.reshape(H, W)

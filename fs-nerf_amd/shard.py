@@ -65,7 +65,11 @@ class FlatGrads:
             self.offsets.append(n)
             n += p.numel()
         self.numel = n
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        # one extra slot behind the gradients: the "an fp16-mode launch of this step overflowed" flag travels in the
+        # SAME all-reduce (sum: > 0 on every rank when any rank raised it), so all ranks skip the update together
+        self._buf = torch.zeros(n + 1, dtype=torch.float32, device=dev)
+        self.flat = self._buf[:n]
+        self.flag_slot = self._buf[n:]
         self.bind()
 
     def view(self, i: int) -> torch.Tensor:
@@ -93,7 +97,10 @@ class FlatGrads:
         self.bind()
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
-        flat = self.flat
+        if self._buf.is_cuda:  # this rank's step flag (device word of the training launches) into the bucket's slot
+            from . import ops
+            self.flag_slot.copy_((ops.step_flag(self._buf.device) & 1).to(torch.float32))
+        flat = self._buf
         if flat.is_cuda and dist.get_backend() == "gloo":  # CPU rehearsal backend: stage through host memory
             host = flat.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM)
@@ -101,7 +108,7 @@ class FlatGrads:
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         if average:
-            flat.div_(dist.get_world_size())
+            self.flat.div_(dist.get_world_size())
 
 
 _buckets = {}

@@ -218,7 +218,12 @@ int fsn_occlusion_reg_bwd(const float* t_vals, int64_t N, const float* ray_sums,
  *   weights / biases / d_weights / d_biases: HOST arrays of n_layers+4 DEVICE pointers in state_dict order
  *   (layers.0.., sigma, connection, branch, rgb); gradients are overwritten, not accumulated.
  *   workspace: fsn_nerf_train_workspace_floats(desc, prec, n) floats, written by _fwd, consumed (and scribbled on)
- *   by _bwd with the same desc / prec / n; out / d_out [n,4] = [rgb, sigma]. */
+ *   by _bwd with the same desc / prec / n; out / d_out [n,4] = [rgb, sigma].
+ *   status: the range-guard word OF THIS STEP AND THIS NETWORK (device, or NULL): the caller zeroes it before _fwd
+ *   and hands the same word to _bwd.  In the fp16 modes _bwd writes this call's gradients as ZEROS when bit 0
+ *   (FSN_STATUS_FP16_RANGE) was raised by either launch (the sums are inf / NaN then); the bf16 modes never consult
+ *   it.  It is NOT a sticky shared word: a flag raised by another network or by an inference launch must not zero
+ *   this network's gradients.  Hand it to fsn_adam_step(skip_word) to skip the update of a flagged step. */
 int64_t fsn_nerf_train_workspace_floats(const fsn_mlp_desc* desc, int prec, int64_t n);
 int fsn_nerf_train_fwd(const fsn_mlp_desc* desc, int prec, const float* const* weights, const float* const* biases,
                        const float* x, const float* dirs, const float* pos_mask, const float* dir_mask,
@@ -237,6 +242,9 @@ int fsn_composite_packed_bwd(const float* sigmas, const float* rgbs, const float
  * fsn_adam_step: torch.optim.Adam's update (no amsgrad), operation for operation in float32, one launch over the
  *   arena: params / grads / exp_avg / exp_avg_sq [n]; `step` = 1, 2, ... (bias corrections are formed in double on
  *   the host); grad_div divides the gradient first (pass the number of ranks when `grads` holds an all-reduced SUM).
+ *   skip_word / skip_count (DEVICE pointers or NULL): the launch leaves parameters and moments untouched when bit 0
+ *   of *skip_word is set or *skip_count > 0 - the per-step status word of fsn_nerf_train_fwd/_bwd (fp16 overflow in
+ *   this step) and the flag slot of an all-reduced gradient bucket; decided on the device, no host sync.
  * fsn_weight_norm_*: the weight-norm "frequency" regulariser of run-nerf.py:266-279: out = sum over the selected
  *   tensors (segments [off, off+len) of the arena, HOST tables, <= 40) of |w|_1 (l2 = 0) or |w|_2 (l2 = 1).
  *   workspace: fsn_weight_norm_workspace_floats(...) floats, written by _fwd and read by _bwd (per-tensor norms);
@@ -244,7 +252,7 @@ int fsn_composite_packed_bwd(const float* sigmas, const float* rgbs, const float
  *   in a fixed order. */
 int fsn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int step,
                   double lr, double beta1, double beta2, double eps, double weight_decay, double grad_div,
-                  fsn_stream_t stream);
+                  const uint32_t* skip_word, const float* skip_count, fsn_stream_t stream);
 int64_t fsn_weight_norm_workspace_floats(int n_seg, const int64_t* seg_len_host);
 int fsn_weight_norm_fwd(const float* arena, int n_seg, const int64_t* seg_off_host, const int64_t* seg_len_host, int l2,
                         float* workspace, float* out, fsn_stream_t stream);

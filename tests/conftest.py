@@ -17,17 +17,3 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
-
-
-@pytest.fixture(scope="session", autouse=True)
-def _reference_fp32_library():
-    """The plain-fp32 (rocBLAS) formulation of the training step the MFMA kernels are checked against is a test-only
-    helper library (tests/ref_fp32); make it known to the host layer for `train_precision="fp32"`."""
-    path = os.path.join(ROOT, "tests", "ref_fp32", "libfsnerf_ref_fp32.so")
-    try:
-        import fs_nerf_amd  # noqa: F401
-        from fs_nerf_amd import _lib
-        _lib.register_reference_library(path)
-    except Exception:
-        pass
-    yield

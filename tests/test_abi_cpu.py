@@ -53,7 +53,7 @@ def test_training_and_occgrid_entry_points_validate_without_gpu():
     w_mfma = lib.fsn_nerf_train_workspace_floats(C.byref(d), L.FSN_PREC_FP16X3, n)
     assert w_mfma > 0
     # the plain-fp32 (library GEMM) formulation is a test helper, not a mode of the product library
-    assert lib.fsn_nerf_train_workspace_floats(C.byref(d), L.FSN_PREC_FP32, n) < 0
+    assert lib.fsn_nerf_train_workspace_floats(C.byref(d), 4, n) < 0  # (4 was the test-only fp32 formulation's code: not a mode of the library)
     assert 4.5e3 * n < w_mfma < 7e3 * n + 5e7 and w_mfma % 1024 == 0
     assert lib.fsn_nerf_train_workspace_floats(C.byref(d), 9, n) < 0 and b"precision" in lib.fsn_last_error()
     assert lib.fsn_nerf_train_workspace_floats(C.byref(d), L.FSN_PREC_FP16X3, -1) < 0

@@ -61,6 +61,39 @@ CFG = {"8x256": dict(n_layers=8, skip=[4], n_freqs=10, n_freqs_dir=4, log_space=
 DIMS = {"8x256": (8, 256), "4x128": (4, 128)}
 
 
+def ndc_error_bound(o, d, hwf, near):
+    """float64 evaluation of to_ndc (utilities.py:84-120) and a first-order bound of the float32 rounding error of
+    its operation sequence, per element.  eps = 2^-24 (half an ulp) per operation."""
+    H, W, focal = hwf
+    o, d = o.astype(np.float64), d.astype(np.float64)
+    eps = 2.0 ** -24
+    with np.errstate(divide="ignore", invalid="ignore"):
+        num = near + o[:, 2]
+        t = -num / d[:, 2]
+        e_t = np.abs(t) * 2 * eps + eps * (np.abs(near) + np.abs(o[:, 2])) / np.abs(d[:, 2])
+        op = o + t[:, None] * d
+        e_op = eps * (np.abs(o) + 2 * np.abs(t[:, None] * d)) + e_t[:, None] * np.abs(d) + eps * np.abs(op)
+        sx, sy = -1.0 / (W / (2.0 * focal)), -1.0 / (H / (2.0 * focal))
+        sc = np.array([sx, sy])
+        r = op[:, :2] / op[:, 2:3]
+        e_r = np.abs(r) * (e_op[:, :2] / np.abs(op[:, :2]).clip(1e-300) + e_op[:, 2:3] / np.abs(op[:, 2:3]) + eps)
+        q = d[:, :2] / d[:, 2:3]
+        e_q = np.abs(q) * eps
+        o01 = sc * r
+        e_o01 = np.abs(sc) * e_r + 2 * eps * np.abs(o01)
+        o2 = 1.0 + 2.0 * near / op[:, 2]
+        e_o2 = np.abs(2.0 * near / op[:, 2]) * (e_op[:, 2] / np.abs(op[:, 2]) + 2 * eps) + eps * np.abs(o2)
+        d01 = sc * (q - r)
+        e_d01 = np.abs(sc) * (e_q + e_r + eps * np.abs(q - r)) + 2 * eps * np.abs(d01)
+        d2 = -2.0 * near / op[:, 2]
+        e_d2 = np.abs(d2) * (e_op[:, 2] / np.abs(op[:, 2]) + 3 * eps)
+    to = np.concatenate([o01, o2[:, None]], -1)
+    td = np.concatenate([d01, d2[:, None]], -1)
+    bo = np.concatenate([e_o01, e_o2[:, None]], -1) + 1e-37
+    bd = np.concatenate([e_d01, e_d2[:, None]], -1) + 1e-37
+    return bo, bd, to, td
+
+
 # ------------------------------------------------------------------ a1/a2/a3 rays
 @pytest.mark.parametrize("pname", ["identity", "orbit0", "orbit3x4", "random"])
 @pytest.mark.parametrize("hname", ["small", "lego100"])
@@ -75,11 +108,26 @@ def test_get_rays_to_ndc_golden(dev, golden_dir, pname, hname):
     close(d, g[key + "_d"], rtol=1e-6, atol=1e-7, what="dirs")
     no, nd = U.to_ndc(torch.from_numpy(g[key + "_o"]).to(dev).reshape(-1, 3),
                       torch.from_numpy(g[key + "_d"]).to(dev).reshape(-1, 3), hwf, 1.0)
-    ok = np.isfinite(g[key + "_ndc_o"]).all(-1) & np.isfinite(g[key + "_ndc_d"]).all(-1)
-    # the projection divides by o_z / d_z: compare where the reference itself is well conditioned
-    ok &= (np.abs(g[key + "_ndc_o"]).max(-1) < 1e3) & (np.abs(g[key + "_ndc_d"]).max(-1) < 1e3)
-    close(no.cpu().numpy()[ok], g[key + "_ndc_o"][ok], rtol=1e-4, atol=1e-4, what="ndc_o")
-    close(nd.cpu().numpy()[ok], g[key + "_ndc_d"][ok], rtol=1e-4, atol=1e-4, what="ndc_d")
+    # to_ndc is 3 divides and a handful of products; its only ill-conditioning is the SINGULAR SET d_z = 0 (ray
+    # parallel to the near plane: t = -(near + o_z) / d_z) and the cancellation in o' = o + t d.  Instead of a blanket
+    # tolerance the test evaluates the first-order rounding-error bound of the reference's operation sequence
+    # (utilities.py:104-114) per element in float64 and allows 1 x that (the reference-generated golden itself sits at
+    # 0.26 x, tools: this test's helper on the CPU): a few float32 ulps wherever the projection is
+    # well conditioned (rtol ~1e-6 on the forward-facing rays it is used for), wider only where the float32 reference
+    # itself is.  Checked against a float64 evaluation AND against the reference-generated golden.
+    bo, bd, to64, td64 = ndc_error_bound(g[key + "_o"].reshape(-1, 3), g[key + "_d"].reshape(-1, 3), hwf, 1.0)
+    ok = np.isfinite(bo).all(-1) & np.isfinite(bd).all(-1) & np.isfinite(g[key + "_ndc_o"]).all(-1) & \
+        np.isfinite(g[key + "_ndc_d"]).all(-1)
+    assert ok.mean() > 0.9 or pname != "identity", "the singular set is a null set"
+    for got, t64, bnd, gold, what in ((no, to64, bo, g[key + "_ndc_o"], "ndc_o"), (nd, td64, bd, g[key + "_ndc_d"], "ndc_d")):
+        got = got.cpu().double().numpy()[ok]
+        assert (np.abs(got - t64[ok]) <= 1.0 * bnd[ok]).all(), \
+            f"{what}: worst {float((np.abs(got - t64[ok]) / bnd[ok]).max()):.2f} x the rounding-error bound"
+        assert (np.abs(got - gold[ok].astype(np.float64)) <= 1.5 * bnd[ok]).all(), f"{what} vs the reference golden"
+    well = ok & (np.abs(g[key + "_d"].reshape(-1, 3)[:, 2]) > 0.1)
+    if well.any():  # forward-facing rays: plain relative tolerance
+        sc = np.abs(to64[well]).max(-1, keepdims=True) + 1.0
+        assert (np.abs(no.cpu().double().numpy()[well] - to64[well]) <= 1e-6 * sc).all(), "ndc_o rtol 1e-6 away from d_z ~ 0"
 
 
 def test_get_rays_row_blocks_and_800(dev):
@@ -145,13 +193,54 @@ def test_sample_pdf_merge(dev, S, NI, det):
     w[::7] = 0.0        # rays with no mass: uniform pdf
     w[3, S // 2:] = -0.2  # negative weights are clamped
     u = None if det else torch.rand(R, NI, generator=gen)
-    want = O.merge_edges(edges, O.sample_pdf(edges, w, NI, u))
     got = ops.sample_pdf_merge(edges.to(dev), w.to(dev), NI, None if u is None else u.to(dev))
     assert got.shape == (R, S + 1 + NI)
     assert bool((got[:, 1:] >= got[:, :-1]).all()), "sorted union"
-    # a sample whose cdf gap sits exactly at the 1e-5 'denom' threshold may flip branch: allow a handful
-    bad = (got.cpu() - want).abs() > (1e-5 + 1e-5 * want.abs())
-    assert bad.float().mean().item() < 1e-3, f"{int(bad.sum())} of {bad.numel()} differ"
+    # Truth = the oracle's arithmetic in float64.  The inverse CDF divides by the mass `denom` of the interval the
+    # sample falls into: an error delta of the float32 cdf (an S-term running sum: bounded by 2 S 2^-24) moves the sample
+    # by delta * width / denom, so THAT is the tolerance, per sample (+ 4 ulps of t): 2e-6 wherever an interval holds
+    # real mass, wider only for the rare samples that land in nearly empty intervals.  The definition is discontinuous
+    # only through the branch `denom < 1e-5 -> 1`: (a) a sample whose denom lies within the cdf error of the
+    # threshold, (b) a sample whose u lies within the cdf error of the END of such a nearly empty interval (inside it
+    # t stays at its left edge, just outside it t continues from its right edge - the deterministic u = 1.0 hits this
+    # whenever the last interval is empty, since cdf[S] rounds to either side of 1).  Rays with such a sample (the tie
+    # set) are excluded from the exact check - they are counted and bounded by one interval width.
+    # Sorting is 1-Lipschitz in the sup norm, so the merged rows are compared with each row's largest tolerance.
+    e64, w64 = edges.double(), torch.clamp(w.double(), min=0.0) + 1e-5
+    pdf = w64 / w64.sum(-1, keepdim=True)
+    cdf = torch.cat([torch.zeros(R, 1, dtype=torch.float64), torch.cumsum(pdf, -1)], -1)
+    uu = (torch.linspace(0.0, 1.0, NI)[None, :].expand(R, NI) if u is None else u).double().contiguous()
+    idx = torch.searchsorted(cdf.contiguous(), uu, right=True)
+    below, above = torch.clamp(idx - 1, min=0), torch.clamp(idx, max=S)
+    c0, c1 = torch.gather(cdf, 1, below), torch.gather(cdf, 1, above)
+    e0, e1 = torch.gather(e64, 1, below), torch.gather(e64, 1, above)
+    raw = c1 - c0
+    den = torch.where(raw < 1e-5, torch.ones_like(raw), raw)
+    t64 = e0 + (uu - c0) / den * (e1 - e0)
+    want64 = torch.sort(torch.cat([e64, t64], -1), -1).values
+    delta = 2.0 * S * 2.0 ** -24  # first-order bound of a float32 running sum of S terms that stays <= 1
+    tol_s = 2e-6 + delta * (e1 - e0) / den
+    big = torch.full_like(raw, 1.0)  # (no interval beyond the ends of the ray)
+    m_prev = torch.where(below > 0, c0 - torch.gather(cdf, 1, torch.clamp(below - 1, min=0)), big)
+    thin = 1e-5 + delta
+    m_cur = torch.where(above > below, raw, big)  # (u >= cdf[S]: below == above == S, no interval of its own)
+    # (u just below c0 sits in the previous interval: discontinuous there iff THAT one is thin; u just below c1 sits
+    # in the current one: discontinuous iff the current one is thin)
+    tie_s = ((m_cur - 1e-5).abs() < delta) | (((uu - c0).abs() < delta) & (m_prev < thin)) | \
+        (((uu - c1).abs() < delta) & (m_cur < thin))
+    tie = tie_s.any(-1)
+    err = (got.cpu().double() - want64).abs().amax(-1)
+    row_tol = tol_s.amax(-1)
+    # (deterministic u ends with u = 1.0 exactly: every ray whose LAST interval is thin - a quarter of these random
+    # rays - is a tie there; with random u ties are rare)
+    assert float(tie.float().mean()) < (0.30 if det else 0.02), "tie rays"
+    bad = (~tie) & (err > row_tol)
+    assert not bool(bad.any()), f"{int(bad.sum())} rays outside the per-sample bound (worst {float((err / row_tol)[~tie].max()):.2f} x)"
+    assert bool((err[tie] <= (6.0 - 2.0) / S + 1e-6).all()), "tie rays: within one coarse interval"
+    # and the float32 oracle sits inside the same bound (the bound is about the arithmetic, not about this kernel)
+    want32 = O.merge_edges(edges, O.sample_pdf(edges, w, NI, u)).double()
+    e32 = (want32 - want64).abs().amax(-1)
+    assert not bool(((~tie) & (e32 > row_tol)).any())
 
 
 # ------------------------------------------------------------------ a7 compositing

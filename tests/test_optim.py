@@ -12,9 +12,9 @@ from fs_nerf_amd import _lib as L
 
 def test_optimizer_entry_points_validate_without_gpu():
     lib = L.lib()
-    assert lib.fsn_adam_step(None, None, None, None, 0, 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0, None) == 0  # n = 0
-    assert lib.fsn_adam_step(None, None, None, None, 8, 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0, None) != 0  # null pointers
-    assert lib.fsn_adam_step(None, None, None, None, 8, 0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0, None) != 0  # step 0
+    assert lib.fsn_adam_step(None, None, None, None, 0, 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0, None, None, None) == 0  # n = 0
+    assert lib.fsn_adam_step(None, None, None, None, 8, 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0, None, None, None) != 0  # null pointers
+    assert lib.fsn_adam_step(None, None, None, None, 8, 0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0, None, None, None) != 0  # step 0
     lens = (C.c_int64 * 2)(10, 20000)
     assert lib.fsn_weight_norm_workspace_floats(2, lens) == 1 + 3 + 40
     assert lib.fsn_weight_norm_workspace_floats(99, lens) < 0
@@ -124,3 +124,54 @@ def test_weight_norm_regulariser_matches_the_reference_formula(reg, arena):
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
     # bit-reproducible (fixed summation order, no atomics)
     assert float(wn()) == float(val)
+
+
+@pytest.mark.gpu
+def test_fused_adam_skips_a_flagged_step_and_checkpoints_its_state():
+    """(1) The device-side step flag (ops.step_flag: an fp16-mode training launch of this step overflowed) or the flag
+    slot of the all-reduced bucket makes the Adam launch a no-op - parameters and both moments untouched - and is
+    consumed by the step.  (2) state_dict / load_state_dict carry the flat moments and the step count: a resumed
+    optimizer continues bit for bit."""
+    import copy
+    from fs_nerf_amd import ops
+    from fs_nerf_amd.core.optim import FusedAdam
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3)).to(dev)
+    opt = FusedAdam(net.parameters(), lr=1e-2)
+    x = torch.randn(16, 7, device=dev)
+
+    def one_step(o, n):
+        o.zero_grad()
+        n(x).square().sum().backward()
+        o.step()
+
+    one_step(opt, net)
+    before = [p.detach().clone() for p in net.parameters()]
+    m0, v0 = opt.exp_avg.clone(), opt.exp_avg_sq.clone()
+    for which in ("word", "slot"):
+        opt.zero_grad()
+        net(x).square().sum().backward()
+        if which == "word":
+            ops.step_flag(dev).fill_(1)
+        else:
+            opt.grads.flag_slot.fill_(2.0)  # two ranks flagged
+        opt.step()
+        for p, b in zip(net.parameters(), before):
+            assert torch.equal(p.detach(), b), f"{which}: a flagged step must not move the parameters"
+        assert torch.equal(opt.exp_avg, m0) and torch.equal(opt.exp_avg_sq, v0), f"{which}: nor the moments"
+        assert int(ops.step_flag(dev).item()) == 0 and float(opt.grads.flag_slot.item()) == 0.0, "flag consumed"
+    one_step(opt, net)
+    assert not torch.equal(next(net.parameters()).detach(), before[0]), "the next clean step updates again"
+    # checkpoint / resume
+    sd_opt, sd_net = copy.deepcopy(opt.state_dict()), copy.deepcopy(net.state_dict())
+    one_step(opt, net)
+    want = [p.detach().clone() for p in net.parameters()]
+    net2 = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3)).to(dev)
+    net2.load_state_dict(sd_net)
+    opt2 = FusedAdam(net2.parameters(), lr=1e-2)
+    opt2.load_state_dict(sd_opt)
+    assert opt2.steps == sd_opt["fused_adam"]["steps"]
+    one_step(opt2, net2)
+    for p, w in zip(net2.parameters(), want):
+        assert torch.equal(p.detach(), w), "resumed optimizer continues bit for bit"

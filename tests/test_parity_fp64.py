@@ -94,8 +94,13 @@ def outputs(res):
             "weights": f(ex["weights"]).reshape(R, -1)}
 
 
-def assert_parity(hip, o32, truth, what, factor=2.0, rtol=RTOL, atol_scale=1.0):
-    """(1) error-size and (2) 1e-4 criteria of the module docstring, for every output."""
+def assert_parity(hip, o32, truth, what, factor=2.0, rtol=RTOL, atol_scale=1.0, tail="elementwise"):
+    """(1) error-size and (2) 1e-4 criteria of the module docstring, for every output.
+    tail="count" (trained networks): the coarse pdf of a trained density is peaked, most importance samples fall into
+    intervals of mass ~1e-4, where the inverse CDF turns a 1e-7 difference of the coarse cdf into a 1e-4 shift of the
+    sample and of the weights on either side of it - in the float32 oracle as in the kernel, in DIFFERENT elements.
+    The float32 oracle is then itself outside 1e-4 on a tail of elements; criterion (2) becomes: HIP's tail is no
+    larger - at most twice as many elements outside the tolerance as the float32 oracle has (+ 1 in 5000)."""
     H, P, T = outputs(hip), outputs(o32), outputs(truth)
     report = {}
     for k in ("rgb_map", "depth_map", "weights", "opacity"):
@@ -110,9 +115,15 @@ def assert_parity(hip, o32, truth, what, factor=2.0, rtol=RTOL, atol_scale=1.0):
             f"{what} {k}: p99 error {np.percentile(eh, 99):.3e} vs float32 oracle's {np.percentile(ep, 99):.3e}"
         tol = rtol * np.abs(T[k]) + atol_scale * ATOL[k]
         ok32 = ep <= tol
-        bad = ok32 & (eh > tol)
-        assert not bad.any(), f"{what} {k}: {int(bad.sum())} of {bad.size} elements outside 1e-4 where the float32 " \
-                              f"oracle is inside (worst {float((eh - tol)[bad].max()):.3e} over)"
+        nh, n32 = int((eh > tol).sum()), int((~ok32).sum())
+        report[k] = report[k] + (nh, n32)
+        if tail == "count":
+            assert nh <= 2 * n32 + eh.size // 5000, f"{what} {k}: {nh} of {eh.size} elements outside 1e-4, the " \
+                                                    f"float32 oracle has {n32}"
+        else:
+            bad = ok32 & (eh > tol)
+            assert not bad.any(), f"{what} {k}: {int(bad.sum())} of {bad.size} elements outside 1e-4 where the float32 " \
+                                  f"oracle is inside (worst {float((eh - tol)[bad].max()):.3e} over)"
         assert ok32.mean() > 0.99, f"{what} {k}: the float32 oracle itself is outside 1e-4 on {1 - ok32.mean():.4f}"
     return report
 
@@ -345,6 +356,57 @@ def test_fp16x3_out_of_range_is_detected_and_rerun_in_bf16x3(dev):
     m2.range_check = False
     m2(pts, dirs)
     assert m2.precision == "fp16x3" and not ops.range_ok(dev)  # ... but the device word still recorded it
+
+
+def test_deferred_range_check_does_not_wait_per_call_and_is_never_silent(dev):
+    """`range_check = "deferred"` (batch rendering in small launches): a call returns without
+    waiting for the GPU; the NEXT call looks at the (asynchronously read back) word of the previous one, warns, switches
+    the models to bf16x3 and renders correctly from then on; a chunked render_frame looks once at its end and renders
+    the frame again.  In-range networks never warn."""
+    from fs_nerf_amd import ops
+    from fs_nerf_amd.render import rendering as Rm
+    L, D, R, S, NI = 8, 256, 96, 64, 128
+    o, d, gen = orbit_rays(R, 12, 800, 1111.111)
+    u, uf = torch.rand(R, generator=gen), torch.rand(R, NI, generator=gen)
+    kw = dict(near=2.0, far=6.0, n_samples=S, n_importance=NI, u=u, u_fine=uf, white_bkgd=True)
+    est = Rm.StratifiedEstimator(2.0, 6.0, S, NI)
+    assert ops.range_ok(dev) and ops.range_poll(dev) == 0
+
+    def models(scale):
+        mc, mf = hip_model(scaled_sd(L, D, 42, scale), L, D, dev, "fp16x3"), hip_model(scaled_sd(L, D, 43, scale), L, D, dev, "fp16x3")
+        mc.range_check = mf.range_check = "deferred"
+        return mc, mf
+
+    render = lambda mc, mf: Rm.render_rays(o, d, est, mc, white_bkgd=True, device=dev, model_fine=mf, u=u.to(dev), u_fine=uf.to(dev))
+    mc, mf = models(1.0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        with torch.no_grad():
+            a, b = render(mc, mf), render(mc, mf)
+    assert torch.equal(a[0][0], b[0][0]) and ops.range_poll(dev) == 0 and mc.precision == "fp16x3"
+    mc, mf = models(4e5)
+    with torch.no_grad():
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            render(mc, mf)  # overflows on the device; nobody has looked yet
+        assert mc.precision == "fp16x3"
+        with pytest.warns(RuntimeWarning, match="EARLIER render_rays call"):
+            good = render(mc, mf)
+    assert mc.precision == "bf16x3" and mf.precision == "bf16x3"
+    sd_c, sd_f = scaled_sd(L, D, 42, 4e5), scaled_sd(L, D, 43, 4e5)
+    truth = oracle(o, d, sd_c, sd_f, cfg_of(L), torch.float64, **kw)
+    o32 = oracle(o, d, sd_c, sd_f, cfg_of(L), torch.float32, **kw)
+    assert_parity(good, o32, truth, "after the deferred fallback", factor=10.0, atol_scale=3.0)
+    assert ops.range_poll(dev) == 0 and ops.range_ok(dev)
+    # chunked frame (foreign estimator path is not needed: an NDC frame goes through get_rays -> to_ndc -> chunks)
+    mc, mf = models(4e5)
+    pose = torch.eye(4)
+    with torch.no_grad():
+        with pytest.warns(RuntimeWarning, match="end of the frame"):
+            img, depth = Rm.render_frame((24, 32, 30.0), 0.0, 1.0, pose, 256, Rm.StratifiedEstimator(0.0, 1.0, 32, 32), mc,
+                                         ndc=True, white_bkgd=True, device=dev, model_fine=mf)
+    assert mc.precision == "bf16x3" and bool(torch.isfinite(img).all()) and bool(torch.isfinite(depth).all())
+    assert ops.range_poll(dev) == 0 and ops.range_ok(dev)
 
 
 # ------------------------------------------------------------------ BASELINE config 5: bf16 weights / activations
