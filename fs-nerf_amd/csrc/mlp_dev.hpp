@@ -99,6 +99,7 @@ struct Frag {  // one k-step (32 features x 16 samples) of activations as MFMA B
 struct WStream {
   char* ring;
   uint32_t ring_lds;  // LDS byte address of the ring (M0 base of the LDS-DMA)
+  uint32_t m0_base;   // ... + this wave's share of a phase (loader waves; SGPR)
   const char *ptrA, *ptrB;
   uint32_t nphA, nphB, repA, repB;
   // stager state
@@ -167,6 +168,7 @@ struct WStream {
                                        uint32_t nB, uint32_t rB) {
     ring = ring_;
     ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring_;
+    m0_base = __builtin_amdgcn_readfirstlane(ring_lds + ((threadIdx.x >> 6) ^ FSN_LOADER_XOR) * (kGldsPerWave * 1024));
     ptrA = pA; nphA = nA; repA = nA ? rA : 0;
     ptrB = pB; nphB = nB; repB = nB ? rB : 0;
     s_rep = 0; s_slot = 0; c_slot = 0;
@@ -199,15 +201,17 @@ struct WStream {
   // stager exactly as stage() does.  phase_lds(k): LDS byte address (+ 16*lane) of the k-th phase counted from the
   // one opened last (k = 0).  opened(n): the block executed n openings.
   __device__ __forceinline__ void next_stage(uint32_t& m0v, uint64_t& gbase) {
-    const uint32_t wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) ^ FSN_LOADER_XOR);
-    m0v = __builtin_amdgcn_readfirstlane(ring_lds + s_slot * kPhaseBytes + wave * (kGldsPerWave * 1024));
-    const uint64_t sp = (uint64_t)s_ptr;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sp);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(sp >> 32));
-    gbase = ((uint64_t)hi << 32) | lo;
+    // (wave-uniform SALU arithmetic only: the M0 base of this wave's share of slot 0 is formed once in init(); the
+    // end of a pass - once in 60..72 stages - is a real branch, not a chain of selects on every stage: the gaps
+    // between the blocks carried ~60 scalar instructions per output pair before, tools/kloop_interblock.py)
+    m0v = m0_base + s_slot * kPhaseBytes;
+    gbase = (uint64_t)s_ptr;
     s_ptr += kPhaseBytes;
     s_slot = slot_add(s_slot, 1);
-    if (--s_left == 0) advance_pass_();
+    if (__builtin_expect(--s_left == 0, 0)) {
+      asm volatile("" ::: "memory");  // keep it a branch (no if-conversion into s_cselect chains)
+      advance_pass_();
+    }
   }
   __device__ __forceinline__ uint32_t phase_lds(uint32_t k) const {
     return ring_lds + slot_add(slot_add(c_slot, kNSlot - 1), k) * kPhaseBytes + (threadIdx.x & 63) * 16;
@@ -334,10 +338,16 @@ template <bool SIGNED>
 __device__ __forceinline__ void range_track(uint32_t& fmax, const s16x8& hi) {
   typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
   const u32x4 w = __builtin_bit_cast(u32x4, hi);
+  if constexpr (!SIGNED) {
+    // non-negative fp16 values order like their bit patterns; infinity (0x7c00) and NaN propagate through the IEEE
+    // maximum: two 3-input packed maxima per pair instead of four 2-input ones
+    asm("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(fmax) : "v"(w[0]), "v"(w[1]));
+    asm("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(fmax) : "v"(w[2]), "v"(w[3]));
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    uint32_t x = w[i];
-    if (SIGNED) x &= 0x7fff7fffu;
+    uint32_t x = w[i] & 0x7fff7fffu;
     asm("v_pk_max_u16 %0, %0, %1" : "+v"(fmax) : "v"(x));
   }
 }
@@ -614,10 +624,15 @@ __device__ __forceinline__ void pair_epilogue(const NetDev& net, int tp, const f
 #endif
       // value = main + 2^-11 x corrections (fp16 modes: exact power-of-two unscaling inside the fma); bf16: scale 1
       constexpr float IK = F16 ? 1.0f / kLoScaleF16 : 1.0f;
+      typedef __attribute__((ext_vector_type(2))) float f32x2;
+      const f32x2 ik2 = {IK, IK};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        v[j] = __builtin_fmaf(cor0[j], IK, acc0[j]);
-        v[4 + j] = __builtin_fmaf(cor1[j], IK, acc1[j]);
+      for (int j = 0; j < 4; j += 2) {  // v_pk_fma_f32: two values per instruction
+        const f32x2 a0 = {acc0[j], acc0[j + 1]}, c0 = {cor0[j], cor0[j + 1]};
+        const f32x2 a1 = {acc1[j], acc1[j + 1]}, c1 = {cor1[j], cor1[j + 1]};
+        const f32x2 r0 = __builtin_elementwise_fma(c0, ik2, a0), r1 = __builtin_elementwise_fma(c1, ik2, a1);
+        v[j] = r0[0]; v[j + 1] = r0[1];
+        v[4 + j] = r1[0]; v[4 + j + 1] = r1[1];
       }
     } else {
 #pragma unroll

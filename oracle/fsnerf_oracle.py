@@ -136,6 +136,36 @@ def round_to(t: Tensor, fmt: Optional[str]) -> Tensor:
     return t.to({"bf16": torch.bfloat16, "fp16": torch.float16}[fmt]).to(t.dtype)
 
 
+def round_e4m3_blocks(t: Tensor, block: int = 32) -> Tensor:
+    """Round to OCP e4m3 under one power-of-two scale per block of `block` consecutive values of the last axis (the
+    operand format of v_mfma_scale_f32_16x16x128_f8f6f4): block maximum scaled into [128, 256)."""
+    n = t.shape[-1]
+    pad = (-n) % block
+    tp = torch.nn.functional.pad(t, (0, pad))
+    b = tp.reshape(*tp.shape[:-1], -1, block)
+    mx = b.abs().amax(-1, keepdim=True).clamp_min(1e-38)
+    sc = torch.exp2(torch.floor(torch.log2(mx)) - 7.0)
+    q = (b / sc).to(torch.float32).to(torch.float8_e4m3fn).to(t.dtype) * sc
+    return q.reshape(tp.shape)[..., :n]
+
+
+def split_linear(h: Tensor, W: Tensor, scheme: str) -> Tensor:
+    """h @ W.T as a split-precision matrix-core GEMM would form it (products exact, sums in h's dtype):
+      "fp16x3"   ah.wh + 2^-11 (al'.wh + ah.wl'), low parts scaled by 2^11 (this build's parity mode, csrc/mlp_layout.hpp)
+      "bf16x3"   the same on bfloat16 parts, unscaled
+      "fp16+f8"  ah.wh in fp16, the two correction products with every operand in block-scaled e4m3 (VERDICT r2 item 4:
+                 a candidate mode, measured in tools/emulate_split.py and DESIGN.md 4.3; NOT built)"""
+    fmt = "bf16" if scheme == "bf16x3" else "fp16"
+    K = 2048.0 if scheme == "fp16x3" else 1.0
+    ah, wh = round_to(h, fmt), round_to(W, fmt)
+    ar, wr = h - ah, W - wh
+    if scheme == "fp16+f8":
+        corr = round_e4m3_blocks(ar) @ round_e4m3_blocks(wh).T + round_e4m3_blocks(ah) @ round_e4m3_blocks(wr).T
+        return ah @ wh.T + corr
+    al, wl = round_to(ar * K, fmt), round_to(wr * K, fmt)
+    return ah @ wh.T + (al @ wh.T + ah @ wl.T) / K
+
+
 def nerf_forward(sd: Dict[str, Tensor], x: Tensor, dirs: Optional[Tensor], *,
                  n_layers: int, skip: Sequence[int], n_freqs: int, n_freqs_dir: int,
                  log_space: bool = True, log_space_dir: Optional[bool] = None,
@@ -145,6 +175,7 @@ def nerf_forward(sd: Dict[str, Tensor], x: Tensor, dirs: Optional[Tensor], *,
     Follows `src/core/models.py:111-143`: relu(layer_i(h)); after layer i in `skip`
     h = cat([h, x_in]); sigma head without activation; connection (no activation);
     cat([feat, dir_enc]); relu(branch); sigmoid(rgb); returns [N,1] or [N,4]=[rgb,sigma].
+    `emulate` = "fp16x3" / "bf16x3" / "fp16+f8": the split-precision schemes of split_linear (float32 x only).
     `emulate` = "bf16" / "fp16" (BASELINE config 5, "bf16 weights/activations"): the same math with the operand
     rounding of a single-pass 16-bit matrix-core kernel restated on the CPU - every Linear layer's weight and input
     are rounded to that format before the product, products and sums are taken in x's dtype (the kernel accumulates
@@ -155,7 +186,10 @@ def nerf_forward(sd: Dict[str, Tensor], x: Tensor, dirs: Optional[Tensor], *,
     dt = x.dtype
     W = lambda k: sd[k].to(dt)
     q = lambda t: round_to(t, emulate)
-    lin = lambda h, k: q(h) @ q(W(k + ".weight")).T + W(k + ".bias")  # a matrix-core GEMM
+    if emulate in ("fp16x3", "bf16x3", "fp16+f8"):  # split-precision schemes (see split_linear)
+        lin = lambda h, k: split_linear(h, W(k + ".weight"), emulate) + W(k + ".bias")
+    else:
+        lin = lambda h, k: q(h) @ q(W(k + ".weight")).T + W(k + ".bias")  # a matrix-core GEMM
     x_in = posenc(x, n_freqs, log_space, pos_mask)
     h = x_in
     for i in range(n_layers):
@@ -297,17 +331,22 @@ def rendering_packed(t_starts: Tensor, t_ends: Tensor, ray_indices: Tensor, n_ra
     dt = t_starts.dtype
     sdt = sigmas * (t_ends - t_starts)
     alphas = 1.0 - torch.exp(-sdt)
-    csum = torch.cumsum(sdt, dim=0)
-    # exclusive sum restarted at every ray boundary
+    # exclusive sum restarted at every ray boundary: a PER-RAY running sum, as nerfacc's scan computes it (a global
+    # cumsum minus the segment's start value cancels catastrophically in float32 after ~1e4 samples)
     first = torch.ones(N, dtype=torch.bool)
     if N > 1:
         first[1:] = ray_indices[1:] != ray_indices[:-1]
-    start_val = torch.zeros(N, dtype=dt)
-    seg_start_csum = (csum - sdt)[first]
     seg_id = torch.cumsum(first.to(torch.int64), 0) - 1
+    excl = torch.zeros(N, dtype=dt)
     if N > 0:
-        start_val = seg_start_csum[seg_id]
-    trans = torch.exp(-((csum - sdt) - start_val))
+        seg_first = torch.nonzero(first).reshape(-1)
+        pos = torch.arange(N) - seg_first[seg_id]
+        n_seg, m = int(seg_id[-1]) + 1, int(pos.max()) + 1
+        dense = torch.zeros(n_seg, m, dtype=dt)
+        dense[seg_id, pos] = sdt
+        run = torch.cumsum(dense, dim=1) - dense
+        excl = run[seg_id, pos]
+    trans = torch.exp(-excl)
     w = trans * alphas
     colors = torch.zeros(n_rays, 3, dtype=dt).index_add_(0, ray_indices, w[:, None] * rgbs)
     opacity = torch.zeros(n_rays, 1, dtype=dt).index_add_(0, ray_indices, w[:, None])

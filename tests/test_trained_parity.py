@@ -80,8 +80,9 @@ def students(dev):
     iters = 400
     # "wnorm_l1": the reference's default norm.  Under Adam its sign-like gradient moves every weight the data term
     # does not defend by ~lr per step, whatever alpha: layers 1-4 end at |w| ~ 2e-4 (1/100 of their initialisation)
-    # with hidden activations ~0.06 - the direction VERDICT r2 named.  "wnorm_l2": the milder per-tensor 2-norm.
-    for name, seed, alpha, norm in (("plain", 22, None, None), ("wnorm_l1", 23, 3e-8, "l1"), ("wnorm_l2", 24, 1e-3, "l2")):
+    # with hidden activations ~0.06 - the direction VERDICT r2 named.  "wnorm_l2": the per-tensor 2-norm at a small
+    # alpha (1e-3 collapsed the hidden layers altogether), a moderately shrunk network.
+    for name, seed, alpha, norm in (("plain", 22, None, None), ("wnorm_l1", 23, 3e-8, "l1"), ("wnorm_l2", 24, 2e-5, "l2")):
         student = make(seed).train()
         est = Rm.StratifiedEstimator(2.0, 6.0, 64, 64).train()
         est.generator = torch.Generator(device=dev).manual_seed(0)
