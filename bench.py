@@ -276,6 +276,105 @@ def train_main(args, rank, world, dev, dist, backend):
         print(json.dumps(line), flush=True)
 
 
+# ---------------------------------------------------------------- occupancy-grid workload (the reference's own render path)
+OCC_RES, OCC_STEP, OCC_RADIUS = 128, 5e-3, 1.477  # sphere holding half of the +-1.5 box's cells; run-nerf.py's step size
+
+
+def occ_main(args, rank, world, dev, dist, backend):
+    """`--workload occgrid`: render_frame with the occupancy estimator in the slot (rendering.py:58-107 as the reference
+    runs it, run-nerf.py:96-98) on a synthetic HALF-EMPTY grid (128^3 cells, the cells inside a sphere of radius 1.477 =
+    50 % occupied), 800x800 orbit frames, render_step_size 5e-3, one 8x256 network: ONE launch per frame
+    (csrc/render_occ.hip).  Reports rays/s, the mean marched / kept samples per ray, and the launch against the MFMA
+    roofline with algorithmic FLOPs = marched samples x 982,528 (density pass) + kept samples x 1,186,816 (full pass);
+    the unfused sequence (5 launches + a host sync) is timed beside it."""
+    from fs_nerf_amd import ops
+    from fs_nerf_amd.render import rendering as Rm
+    from fs_nerf_amd.render.occgrid import OccGridEstimator
+    from fs_nerf_amd.utils import utilities as U
+    model = init_sd(42)
+    with torch.no_grad():
+        model.sigma.bias.add_(27.0)  # an opaque medium (sigma ~ 30): rays saturate after ~60 of their ~350 marched samples
+    model.precision = args.precision
+    model.to(dev).eval()
+    est = OccGridEstimator(roi_aabb=torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5]), resolution=OCC_RES, levels=1).to(dev)
+    ax = (torch.arange(OCC_RES) + 0.5) / OCC_RES * 3.0 - 1.5
+    x, y, z = torch.meshgrid(ax, ax, ax, indexing="ij")
+    est.set_binaries(((x * x + y * y + z * z).sqrt() < OCC_RADIUS)[None])
+    est.eval()
+    occupied = float(est.binaries.float().mean())
+    ops.launch_timer = ev_raw = []
+
+    def step(i, timed):
+        pose = orbit_pose(((i * world + rank) % 90) * 4.0)
+        n0 = len(ev_raw)
+        with torch.no_grad():
+            out = Rm.render_frame((H, W, FOCAL), NEAR, FAR, pose, 1 << 30, est, model, white_bkgd=True,
+                                  render_step_size=OCC_STEP, device=dev)
+        if not timed:
+            del ev_raw[n0:]
+        return out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i, False)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i, True)
+    barrier()
+    dt = time.perf_counter() - t0
+    assert bool(torch.isfinite(out[0]).all()) and ops.range_ok(dev) and model.precision == args.precision
+    if world > 1:
+        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev_raw) / max(len(ev_raw), 1)
+    ops.launch_timer = None
+    if rank == 0:
+        # sample counts of the last timed frame + the unfused sequence on the same frame (outside the timed region)
+        pose = orbit_pose((((args.warmup + args.steps - 1) * world + rank) % 90) * 4.0)
+        cam = (pose, H, W, FOCAL, 0, H, dev)
+        _, _, _, cnt = ops.render_occ_fused(model.packed(), None, None, aabb=est.aabb, res=est.resolution, levels=1,
+                                            bits=est.bits, near_plane=0.0, far_plane=1e10, step=OCC_STEP,
+                                            max_steps=est.max_steps(OCC_STEP), bkgd=(1.0, 1.0, 1.0), camera=cam,
+                                            want_counts=True)
+        n_cand, n_kept = float(cnt["n_cand"].float().mean()), float(cnt["n_kept"].float().mean())
+        o, d = U.get_rays(pose, (H, W, FOCAL), dev)
+        o, d = o.reshape(-1, 3), d.reshape(-1, 3)
+        torch.cuda.synchronize()
+        tu = time.perf_counter()
+        with torch.no_grad():
+            (rgb_u, _, _, _), _, _ = Rm.render_rays(o, d, est, model, white_bkgd=True, render_step_size=OCC_STEP, device=dev)
+        torch.cuda.synchronize()
+        unfused_ms = (time.perf_counter() - tu) * 1e3
+        same = bool(torch.equal(rgb_u, out[0].reshape(-1, 3)))
+        flop_per_ray = n_cand * FLOP_DENSITY + n_kept * FLOP_FULL
+        achieved = flop_per_ray * H * W / (kern_ms * 1e-3) / 1e12
+        value = world * args.steps * H * W / dt
+        line = {
+            "metric": "rendered rays/sec (occupancy-grid estimator, render_step_size 5e-3, 8x256 MLP)", "value": value,
+            "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "Lego-style orbit 800x800 (focal 1111.11), occupancy estimator: 128^3 cells over the "
+                                   "+-1.5 box, the cells inside a sphere of radius 1.477 occupied, render_step_size 5e-3, "
+                                   "early_stop_eps 1e-4, one 8x256 NeRF (seed 42, sigma head x64 + 30: opaque), render_frame = ONE launch (march -> "
+                                   "density pass -> visibility -> full pass -> packed integration), rays generated in it",
+                       "rays_per_step": H * W, "occupied_cells": occupied, "marched_samples_per_ray": n_cand,
+                       "kept_samples_per_ray": n_kept, "parallelism": f"rays x{world} (no data-path collective)",
+                       "unfused_sequence_ms": unfused_ms, "fused_equals_unfused_bitwise": same},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_TFLOPS, "traffic": None, "kernel": "k_render_occ", "kernel_ms": kern_ms,
+                         "flop_per_ray": flop_per_ray,
+                         "passes_per_product": 3 if args.precision.endswith("x3") else 1},
+        }
+        print(json.dumps(line), flush=True)
+
+
 # ---------------------------------------------------------------- N>1 self-launcher
 def _free_port():
     import socket
@@ -399,7 +498,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", choices=("render", "train"), default="render")
+    ap.add_argument("--workload", choices=("render", "train", "occgrid"), default="render")
     ap.add_argument("--precision", default=os.environ.get("FSN_BENCH_PREC", "fp16x3"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
@@ -410,9 +509,9 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="launcher self-test on the CPU (gloo); not a measurement")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 3 if args.workload == "render" else 20
+        args.steps = 20 if args.workload == "train" else 3
     if args.warmup is None:
-        args.warmup = 1 if args.workload == "render" else 3
+        args.warmup = 3 if args.workload == "train" else 1
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -438,8 +537,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    if args.workload == "train":
-        train_main(args, rank, world, dev, dist, backend)
+    if args.workload in ("train", "occgrid"):
+        (train_main if args.workload == "train" else occ_main)(args, rank, world, dev, dist, backend)
         if world > 1:
             dist.destroy_process_group()
         return

@@ -38,6 +38,18 @@ class RenderArgs(C.Structure):
                 ("cam_focal", C.c_double), ("two_phase", C.c_int32)]
 
 
+class OccRenderArgs(C.Structure):
+    _fields_ = [("rays_o", C.c_void_p), ("rays_d", C.c_void_p), ("R", C.c_int64), ("aabb", C.c_float * 6),
+                ("res", C.c_int32), ("levels", C.c_int32), ("bits", C.c_void_p),
+                ("near_plane", C.c_float), ("far_plane", C.c_float), ("step", C.c_float), ("u", C.c_void_p),
+                ("max_steps", C.c_int32), ("early_stop_eps", C.c_float), ("alpha_thre", C.c_float),
+                ("pos_mask", C.c_void_p), ("dir_mask", C.c_void_p), ("bkgd", C.c_float * 3),
+                ("colors", C.c_void_p), ("opacity", C.c_void_p), ("depth", C.c_void_p),
+                ("n_cand", C.c_void_p), ("n_kept", C.c_void_p), ("status", C.c_void_p), ("work_counter", C.c_void_p),
+                ("cam_pose", C.c_float * 12), ("cam_H", C.c_int32), ("cam_W", C.c_int32), ("cam_row0", C.c_int32),
+                ("cam_focal", C.c_double)]
+
+
 _vp, _i, _i64, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 _PD = C.POINTER(MlpDesc)
 
@@ -59,6 +71,7 @@ SIGNATURES = {
     "fsn_mlp_pack_host": (_i, [_PD, _i, _vp, _vp, _vp]),
     "fsn_mlp_fwd": (_i, [_PD, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "fsn_render_rays_fused": (_i, [_PD, _i, _vp, _vp, C.POINTER(RenderArgs), _vp]),
+    "fsn_render_rays_occgrid": (_i, [_PD, _i, _vp, C.POINTER(OccRenderArgs), _vp]),
     "fsn_occlusion_reg_fwd": (_i, [_vp, _vp, _vp, _i64, _i64, _f, _f, _i, _vp, _vp, _vp]),
     "fsn_to8b": (_i, [_vp, _i64, _vp, _vp]),
     "fsn_to8b_nchw": (_i, [_vp, _i64, _i64, _vp, _vp]),

@@ -178,6 +178,12 @@ struct WStream {
     for (int i = 0; i < kLook; ++i) stage();
     if (kLead > 0) open_next();  // every pass finds its first phase already opened
   }
+  // Data-dependent schedules (render_occ.hip: the number of density-only and full tiles of a batch is only known
+  // while it runs).  Both kinds of tile stream the SAME blob from its first phase and differ in where they stop, so the
+  // stager can always wrap to phase 0; a tile says how long it is when it starts.  At that moment exactly kLook + 1
+  // phases of it are staged (the invariant of init() / the phase openings).  init() with nphB = kDynamicPhases.
+  static constexpr uint32_t kDynamicPhases = 1u << 30;
+  __device__ __forceinline__ void begin_tile(uint32_t nph) { s_left = nph - (uint32_t)(kLook + 1); }
   // Open the next phase: its loads have landed for every wave (vmcnt counts in issue order, so
   // allowing the (kLook-1)*kGldsPerWave youngest loads to stay in flight retires exactly the oldest
   // staged phase), every wave is past the phase whose slot is restaged next.

@@ -15,43 +15,10 @@
 //    alpha_i >= alpha_thre.
 //  * update: occs[c] = max(occs[c]*decay, occ_c) for the evaluated cells; bit = occs > threshold.
 #include "common.hpp"
+#include "occ_dev.hpp"
 #include "ray_dev.hpp"
 
 namespace fsn {
-
-struct GridDev {
-  float amin[3], amax[3];  // region of interest (level 0)
-  int32_t res, levels;
-};
-
-// occupancy of the cell holding point p: finest level whose box contains p; false outside all boxes
-__device__ __forceinline__ bool grid_occupied(const GridDev& G, const uint32_t* __restrict__ bits, float px, float py,
-                                              float pz) {
-  const float p[3] = {px, py, pz};
-  float c[3], h[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    c[a] = (G.amin[a] + G.amax[a]) / 2.0f;
-    h[a] = (G.amax[a] - G.amin[a]) / 2.0f;
-  }
-  float s = 1.0f;
-  for (int l = 0; l < G.levels; ++l, s *= 2.0f) {
-    bool in = true;
-    int ci[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float lo = c[a] - h[a] * s, hi = c[a] + h[a] * s;
-      in = in && p[a] >= lo && p[a] <= hi;
-      int q = (int)floorf((p[a] - lo) / (hi - lo) * (float)G.res);
-      ci[a] = min(max(q, 0), G.res - 1);
-    }
-    if (in) {
-      const int64_t cell = (int64_t)l * G.res * G.res * G.res + ((int64_t)ci[0] * G.res + ci[1]) * G.res + ci[2];
-      return (bits[cell >> 5] >> (cell & 31)) & 1u;
-    }
-  }
-  return false;
-}
 
 // pass 0: counts[r]; pass 1: fill ray_indices / t_starts / t_ends at offsets[r]
 template <bool FILL>
@@ -65,52 +32,16 @@ __global__ void k_occ_march(const float* __restrict__ rays_o, const float* __res
   if (r >= R) return;
   const float o[3] = {rays_o[3 * r], rays_o[3 * r + 1], rays_o[3 * r + 2]};
   const float d[3] = {rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]};
-  // slab intersection with the outermost box
-  const float sc = (float)(1 << (G.levels - 1));
-  float tmin = -__builtin_huge_valf(), tmax = __builtin_huge_valf();
-  bool miss = false;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    const float c = (G.amin[a] + G.amax[a]) / 2.0f, h = (G.amax[a] - G.amin[a]) / 2.0f * sc;
-    const float lo = c - h, hi = c + h;
-    if (d[a] == 0.0f) {
-      miss = miss || o[a] < lo || o[a] > hi;
-    } else {
-      const float ta = (lo - o[a]) / d[a], tb = (hi - o[a]) / d[a];
-      tmin = fmaxf(tmin, fminf(ta, tb));
-      tmax = fminf(tmax, fmaxf(ta, tb));
+  const RayLattice L = ray_lattice(G, o, d, near_plane, far_plane, step, u != nullptr, u ? u[r] : 0.f);
+  const int64_t base_out = FILL ? offsets[r] : 0;
+  const int total = march_ray(G, bits, o, d, L, step, max_steps, [&](float ts, float te, bool keep, uint64_t m, int before) {
+    if (FILL && keep) {
+      const int64_t pos = base_out + before + __popcll(m & ((1ull << lane) - 1ull));
+      ray_indices[pos] = r;
+      t_starts[pos] = ts;
+      t_ends[pos] = te;
     }
-  }
-  const float near_r = u ? near_plane + u[r] * step : near_plane;
-  const float t_lo = fmaxf(tmin, near_r), t_hi = fminf(tmax, far_plane);
-  int64_t total = 0;
-  if (!miss && t_hi > t_lo) {
-    int k0 = (int)ceilf((t_lo - near_r) / step);
-    if (k0 < 0) k0 = 0;
-    const int64_t base_out = FILL ? offsets[r] : 0;
-    for (int it = 0; it < max_steps; it += 64) {
-      const int k = k0 + it + lane;
-      const float ts = near_r + (float)k * step;
-      const float te = ts + step;
-      const bool in_range = (it + lane) < max_steps && ts >= t_lo && ts < t_hi;
-      bool keep = false;
-      if (in_range) {
-        const float tm = (ts + te) / 2.0f;
-        keep = grid_occupied(G, bits, o[0] + d[0] * tm, o[1] + d[1] * tm, o[2] + d[2] * tm);
-      }
-      const uint64_t m = __ballot(keep);
-      if (FILL && keep) {
-        const int64_t pos = base_out + total + __popcll(m & ((1ull << lane) - 1ull));
-        ray_indices[pos] = r;
-        t_starts[pos] = ts;
-        t_ends[pos] = te;
-      }
-      total += __popcll(m);
-      // wave-uniform exit: the first lane's lattice point of the NEXT iteration is already past the box
-      const float ts_next = near_r + (float)(k0 + it + 64) * step;
-      if (!(ts_next < t_hi)) break;
-    }
-  }
+  });
   if (!FILL && lane == 0) counts[r] = total;
 }
 
@@ -159,18 +90,6 @@ __global__ void k_occ_binarize(const float* __restrict__ occs, int64_t n_cells, 
   const int lane = threadIdx.x & 63;
   if (lane == 0 && c < n_cells) bits[c >> 5] = (uint32_t)m;
   if (lane == 32 && c < n_cells) bits[c >> 5] = (uint32_t)(m >> 32);
-}
-
-static int make_grid(const float* aabb_host, int res, int levels, GridDev& G) {
-  FSN_REQUIRE(aabb_host, FSN_E_INVALID, "occupancy grid: null aabb");
-  FSN_REQUIRE(res >= 1 && res <= 1024 && levels >= 1 && levels <= 8, FSN_E_INVALID, "occupancy grid: bad resolution / levels");
-  for (int a = 0; a < 3; ++a) {
-    G.amin[a] = aabb_host[a];
-    G.amax[a] = aabb_host[3 + a];
-    FSN_REQUIRE(G.amax[a] > G.amin[a], FSN_E_INVALID, "occupancy grid: empty aabb");
-  }
-  G.res = res; G.levels = levels;
-  return FSN_OK;
 }
 
 }  // namespace fsn

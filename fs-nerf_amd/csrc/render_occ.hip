@@ -1,0 +1,356 @@
+// render_occ.hip — the path the reference itself renders with (src/render/rendering.py:58-107 with nerfacc's
+// OccGridEstimator in the estimator slot, src/run-nerf.py:96-98, 288-295) in ONE launch, without a host sync for the
+// data-dependent sample count:
+//   occupancy-grid march -> density pass (sigma_fn) -> visibility cull -> full pass (rgb_sigma_fn) -> packed volume
+//   integration,
+// per BATCH of rays inside a persistent workgroup.  A batch is as many whole rays as fit the LDS sample list
+// (kCap samples, kMaxRays rays), pulled in chunks of 8 (one wave marches one ray) from a global work counter, so that
+// dense and empty rays balance across the chip; a ray that no longer fits is carried into the next batch.  The sample
+// list, densities, keep flags, colours live in LDS; the two MLP passes run on the matrix cores over 128-sample tiles
+// of the list (mlp_dev.hpp) with the weight stream running on from tile to tile and batch to batch - both kinds of
+// tile stream the same blob from its first phase, a tile announces its length when it starts (WStream::begin_tile).
+// HBM traffic: the rays in (or none: generated from the pose), 20 B per ray out, the bit grid through L2.
+// Every sample is evaluated independently of its tile position and every ray is integrated by one wave with the
+// arithmetic of the standalone kernels (occ_dev.hpp, ray_dev.hpp): the image does not depend on how batches form and is
+// the unfused path's (march -> k_mlp_fwd -> k_visibility -> k_mlp_fwd -> k_composite_packed).
+#include "common.hpp"
+#define FSN_KLOOP_ASM
+#include "mlp_dev.hpp"
+#include "occ_dev.hpp"
+#include "ray_dev.hpp"
+
+namespace fsn {
+
+constexpr int kCap = 2048;      // samples of a batch (candidates; kept samples are a subset)
+constexpr int kMaxRays = 128;   // rays of a batch
+
+struct OccKArgs {
+  NetParams net;
+  fsn_occ_render_args a;
+  GridDev G;
+  float cam_hw, cam_hh, cam_f;
+  int32_t use_vis;
+};
+
+struct OccLds {
+  fsn_occ_render_args a;
+  GridDev G;
+  float cam_hw, cam_hh, cam_f;
+  int32_t use_vis;
+  // batch state (written by thread 0 between barriers)
+  int64_t chunk_base, carry_base;
+  int32_t chunk_from, carry_from, stop, n_cand, n_kept, n_rays;
+  int32_t cnt[kWaves];
+  // rays of the batch
+  float rays[kMaxRays * 6];
+  int64_t ray_id[kMaxRays];
+  int32_t cand_off[kMaxRays], cand_cnt[kMaxRays], kept_off[kMaxRays + 1], kept_cnt[kMaxRays];
+  // candidate samples (march order: sorted by ray slot, then t)
+  float t0c[kCap], sigc[kCap];
+  uint16_t slotc[kCap];
+  uint8_t keepf[kCap];
+  // kept samples
+  float t0k[kCap], t1k[kCap], sigk[kCap], rgbk[3 * kCap];
+  uint16_t slotk[kCap];
+};
+
+constexpr int kOccLdsBytes = kRingBytes + (kAuxCapFloats + 96) * 4 + (int)sizeof(OccLds);
+static_assert(kOccLdsBytes <= 160 * 1024, "LDS budget");
+
+// sample source: interval [t0, t0 + step) of ray `ray`: x = o + d (t0 + t1) / 2 (rendering.py:59-61, 77-79)
+struct OccSrc {
+  const float* ray;
+  float t0, step;
+  __device__ __forceinline__ void pos(float& x, float& y, float& z) const {
+    const float tm = t0 + (t0 + step);
+    x = ray[0] + ray[3] * tm / 2.0f;
+    y = ray[1] + ray[4] * tm / 2.0f;
+    z = ray[2] + ray[5] * tm / 2.0f;
+  }
+  __device__ __forceinline__ void dir(float& x, float& y, float& z) const { x = ray[3]; y = ray[4]; z = ray[5]; }
+};
+
+// exclusive prefix sum of an int over the 64 lanes; total to all
+__device__ __forceinline__ int wave_excl_scan_i(int v, int& total) {
+  const int lane = lane_id();
+  int inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  total = __shfl(inc, 63, 64);
+  return inc - v;
+}
+
+template <int NT, int PREC>
+__global__ __launch_bounds__(kThreads) void k_render_occ(OccKArgs k) {
+  __shared__ __attribute__((aligned(1024))) char smem[kOccLdsBytes];
+  float* aux = reinterpret_cast<float*>(smem + kRingBytes);
+  OccLds& S = *reinterpret_cast<OccLds*>(smem + kRingBytes + (kAuxCapFloats + 96) * 4);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid == 0) {
+    S.a = k.a; S.G = k.G; S.cam_hw = k.cam_hw; S.cam_hh = k.cam_hh; S.cam_f = k.cam_f; S.use_vis = k.use_vis;
+    S.carry_from = kWaves; S.carry_base = 0;
+  }
+  __syncthreads();
+  const fsn_occ_render_args& a = S.a;
+  NetDev net;
+  load_net(k.net, a.pos_mask, a.dir_mask, aux, net);
+  __syncthreads();
+  WStream st;
+  st.init(smem, nullptr, 0, 0, k.net.blob + k.net.stream_off, WStream::kDynamicPhases, 1);
+  const uint32_t nph_density = (uint32_t)k.net.nph_density, nph_full = (uint32_t)k.net.nph_full;
+  ARing ring;
+  prime_ring<PREC, NT>(st, ring);
+
+  // this wave's ray of a chunk -> registers (every lane holds the same values)
+  auto fetch_ray = [&](int64_t ray, float (&o)[3], float (&d)[3]) {
+    if (a.rays_o) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { o[c] = a.rays_o[3 * ray + c]; d[c] = a.rays_d[3 * ray + c]; }
+    } else {
+      const int h = a.cam_row0 + (int)(ray / a.cam_W), w = (int)(ray % a.cam_W);
+      pinhole_ray(a.cam_pose, S.cam_hw, S.cam_hh, S.cam_f, h, w, o, d);
+    }
+  };
+
+  for (;;) {
+    // ------------------------------------------------------------ build a batch
+    if (tid == 0) { S.n_cand = 0; S.n_rays = 0; S.stop = 0; }
+    __syncthreads();
+    for (;;) {
+      if (tid == 0) {
+        if (S.carry_from < kWaves) {
+          S.chunk_base = S.carry_base; S.chunk_from = S.carry_from; S.carry_from = kWaves;
+        } else {
+          S.chunk_base = (int64_t)atomicAdd(reinterpret_cast<unsigned long long*>(a.work_counter), (unsigned long long)kWaves);
+          S.chunk_from = 0;
+        }
+      }
+      __syncthreads();
+      const int64_t base = S.chunk_base;
+      const int from = S.chunk_from;
+      if (base >= a.R) break;  // (workgroup-uniform: read from LDS)
+      const int64_t ray = base + wave;
+      const bool active = wave >= from && ray < a.R;
+      float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 1.f};
+      RayLattice L;
+      L.any = false; L.near_r = L.t_lo = L.t_hi = 0.f; L.k0 = 0;
+      int c = 0;
+      if (active) {
+        fetch_ray(ray, o, d);
+        L = ray_lattice(S.G, o, d, a.near_plane, a.far_plane, a.step, a.u != nullptr, a.u ? a.u[ray] : 0.f);
+        c = march_ray(S.G, a.bits, o, d, L, a.step, a.max_steps, [](float, float, bool, uint64_t, int) {});
+      }
+      if (lane == 0) S.cnt[wave] = active ? c : -1;
+      __syncthreads();
+      // accept the chunk's rays in order while they fit (every thread evaluates the same recurrence)
+      int nc = S.n_cand, nr = S.n_rays, my_off = -1, my_slot = 0, first_rej = kWaves;
+      bool stop = false;
+      for (int w = from; w < kWaves; ++w) {
+        const int cw = S.cnt[w];
+        if (cw < 0) continue;
+        if (!stop && nr < kMaxRays && nc + cw <= kCap) {
+          if (w == wave) { my_off = nc; my_slot = nr; }
+          nc += cw;
+          nr += 1;
+        } else if (!stop) {
+          stop = true;
+          first_rej = w;
+        }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        S.n_cand = nc; S.n_rays = nr;
+        if (stop) { S.carry_base = base; S.carry_from = first_rej; S.stop = 1; }
+      }
+      if (my_off >= 0) {
+        if (lane == 0) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) { S.rays[6 * my_slot + q] = o[q]; S.rays[6 * my_slot + 3 + q] = d[q]; }
+          S.ray_id[my_slot] = ray;
+          S.cand_off[my_slot] = my_off;
+          S.cand_cnt[my_slot] = c;
+        }
+        march_ray(S.G, a.bits, o, d, L, a.step, a.max_steps, [&](float ts, float, bool keep, uint64_t m, int before) {
+          if (keep) {
+            const int pos = my_off + before + __popcll(m & ((1ull << lane) - 1ull));
+            S.t0c[pos] = ts;
+            S.slotc[pos] = (uint16_t)my_slot;
+          }
+        });
+      }
+      __syncthreads();
+      if (S.stop) break;
+    }
+    const int n_rays = S.n_rays, n_cand = S.n_cand;
+    if (n_rays == 0) break;  // no ray left for this workgroup (uniform)
+
+    // ------------------------------------------------------------ density pass + visibility (estimator.sampling)
+    if (S.use_vis && n_cand > 0) {
+      for (int sub = 0; sub * 128 < n_cand; ++sub) {
+        const int idx = sub * 128 + wave * 16 + (lane & 15);
+        const int ic = min(idx, n_cand - 1);
+        const OccSrc src{S.rays + 6 * S.slotc[ic], S.t0c[ic], a.step};
+        float sigma, rgb[3];
+        st.begin_tile(nph_density);
+        mlp_tile<NT, PREC, false>(st, net, src, ring, sigma, rgb);
+        if (lane < 16 && idx < n_cand) S.sigc[idx] = sigma;
+      }
+      lds_barrier();
+      // keep flags per ray: the arithmetic of k_visibility (occgrid.hip), one wave per ray
+      for (int r = wave; r < n_rays; r += kWaves) {
+        const int Sn = S.cand_cnt[r], beg = S.cand_off[r];
+        const int per = (Sn + 63) >> 6;
+        const int i0 = lane * per, i1 = min(i0 + per, Sn);
+        float lsum = 0.f;
+        for (int i = i0; i < i1; ++i) lsum += S.sigc[beg + i] * ((S.t0c[beg + i] + a.step) - S.t0c[beg + i]);
+        float tot;
+        float run = wave_excl_scan(lsum, tot);
+        int nk = 0;
+        for (int i = i0; i < i1; ++i) {
+          const float sdt = S.sigc[beg + i] * ((S.t0c[beg + i] + a.step) - S.t0c[beg + i]);
+          const float T = expf(-run), alpha = 1.0f - expf(-sdt);
+          const bool kp = T >= a.early_stop_eps && alpha >= a.alpha_thre;
+          S.keepf[beg + i] = kp ? 1 : 0;
+          nk += kp ? 1 : 0;
+          run += sdt;
+        }
+        int tk;
+        wave_excl_scan_i(nk, tk);
+        if (lane == 0) S.kept_cnt[r] = tk;
+      }
+    } else {
+      for (int i = tid; i < n_cand; i += kThreads) S.keepf[i] = 1;
+      for (int r = tid; r < n_rays; r += kThreads) S.kept_cnt[r] = S.cand_cnt[r];
+    }
+    lds_barrier();
+    if (wave == 0) {  // exclusive scan of the kept counts over the batch's rays (<= 128: two per lane)
+      const int c0 = 2 * lane < n_rays ? S.kept_cnt[2 * lane] : 0, c1 = 2 * lane + 1 < n_rays ? S.kept_cnt[2 * lane + 1] : 0;
+      int tot;
+      const int ex = wave_excl_scan_i(c0 + c1, tot);
+      if (2 * lane < n_rays) S.kept_off[2 * lane] = ex;
+      if (2 * lane + 1 < n_rays) S.kept_off[2 * lane + 1] = ex + c0;
+      if (lane == 0) S.n_kept = tot;
+    }
+    lds_barrier();
+    for (int r = wave; r < n_rays; r += kWaves) {  // compaction, order preserved
+      const int Sn = S.cand_cnt[r], beg = S.cand_off[r], ko = S.kept_off[r];
+      const int per = (Sn + 63) >> 6;
+      const int i0 = lane * per, i1 = min(i0 + per, Sn);
+      int nk = 0;
+      for (int i = i0; i < i1; ++i) nk += S.keepf[beg + i];
+      int tk;
+      int pos = ko + wave_excl_scan_i(nk, tk);
+      for (int i = i0; i < i1; ++i) {
+        if (S.keepf[beg + i]) {
+          const float t0 = S.t0c[beg + i];
+          S.t0k[pos] = t0;
+          S.t1k[pos] = t0 + a.step;
+          S.slotk[pos] = (uint16_t)r;
+          ++pos;
+        }
+      }
+    }
+    lds_barrier();
+    // ------------------------------------------------------------ full pass (rgb_sigma_fn) + packed integration
+    const int n_kept = S.n_kept;
+    for (int sub = 0; sub * 128 < n_kept; ++sub) {
+      const int idx = sub * 128 + wave * 16 + (lane & 15);
+      const int ic = min(idx, n_kept - 1);
+      const OccSrc src{S.rays + 6 * S.slotk[ic], S.t0k[ic], a.step};
+      float sigma, rgb[3];
+      st.begin_tile(nph_full);
+      mlp_tile<NT, PREC, true>(st, net, src, ring, sigma, rgb);
+      if (lane < 16 && idx < n_kept) {
+        S.sigk[idx] = sigma;
+        S.rgbk[3 * idx + 0] = rgb[0];
+        S.rgbk[3 * idx + 1] = rgb[1];
+        S.rgbk[3 * idx + 2] = rgb[2];
+      }
+    }
+    lds_barrier();
+    for (int r = wave; r < n_rays; r += kWaves) {
+      const int64_t ray = S.ray_id[r];
+      const int ko = S.kept_off[r], Sk = S.kept_cnt[r];
+      CompositeOut o{a.colors + 3 * ray, a.opacity + ray, a.depth + ray, nullptr, nullptr, nullptr};
+      composite_ray(S.sigk + ko, S.rgbk + 3 * ko, S.t0k + ko, S.t1k + ko, Sk, true, a.bkgd[0], a.bkgd[1], a.bkgd[2], o);
+      if (lane == 0) {
+        if (a.n_cand) a.n_cand[ray] = S.cand_cnt[r];
+        if (a.n_kept) a.n_kept[ray] = Sk;
+      }
+    }
+    lds_barrier();
+  }
+  st.drain();
+}
+
+template <int NT, int PREC>
+static int launch_occ(const OccKArgs& k, int cus, hipStream_t s) {
+  const int64_t chunks = (k.a.R + kWaves - 1) / kWaves;
+  const unsigned grid = (unsigned)(chunks < cus ? chunks : cus);
+  k_render_occ<NT, PREC><<<grid, kThreads, 0, s>>>(k);
+  FSN_LAUNCH_CHECK("k_render_occ");
+  return FSN_OK;
+}
+
+}  // namespace fsn
+
+using namespace fsn;
+
+extern "C" int fsn_render_rays_occgrid(const fsn_mlp_desc* desc, int prec, const void* blob,
+                                       const fsn_occ_render_args* args, fsn_stream_t stream) {
+  FSN_REQUIRE(desc && args, FSN_E_INVALID, "fsn_render_rays_occgrid: null pointer");
+  const fsn_occ_render_args& a = *args;
+  FSN_REQUIRE(a.R >= 0 && a.step > 0.f && a.max_steps > 0, FSN_E_INVALID, "fsn_render_rays_occgrid: bad sizes");
+  FSN_REQUIRE(prec >= 0 && prec <= FSN_PREC_FP16, FSN_E_UNSUPPORTED, "fsn_render_rays_occgrid: precision mode %d", prec);
+  NetGeom G;
+  const char* why;
+  int rc = build_geom(*desc, prec, G, &why);
+  FSN_REQUIRE(rc == FSN_OK, rc, "fsn_render_rays_occgrid: %s", why);
+  OccKArgs k;
+  rc = make_grid(a.aabb, a.res, a.levels, k.G);
+  if (rc != FSN_OK) return rc;
+  if (a.R == 0) return FSN_OK;
+  FSN_REQUIRE(blob && a.bits && a.colors && a.opacity && a.depth && a.work_counter, FSN_E_INVALID,
+              "fsn_render_rays_occgrid: null pointer");
+  FSN_REQUIRE(a.max_steps <= kCap, FSN_E_UNSUPPORTED,
+              "fsn_render_rays_occgrid: max_steps %d > %d samples of one ray group (use the unfused path)", a.max_steps, kCap);
+  if (a.rays_o) {
+    FSN_REQUIRE(a.rays_d, FSN_E_INVALID, "fsn_render_rays_occgrid: rays_o without rays_d");
+  } else {
+    FSN_REQUIRE(a.cam_H > 0 && a.cam_W > 0 && a.cam_focal > 0 && a.cam_row0 >= 0 &&
+                    a.R <= (int64_t)(a.cam_H - a.cam_row0) * a.cam_W,
+                FSN_E_INVALID, "fsn_render_rays_occgrid: no rays and no valid camera");
+  }
+  FSN_REQUIRE(G.aux_floats <= kAuxCapFloats, FSN_E_UNSUPPORTED, "fsn_render_rays_occgrid: network too deep for LDS");
+  NetParams p;
+  p.blob = static_cast<const char*>(blob);
+  p.aux_off = (int32_t)G.aux_off; p.aux_floats = G.aux_floats; p.stream_off = (int32_t)G.stream_off;
+  p.nph_density = G.nph_density; p.nph_full = G.nph_full;
+  p.n_layers = desc->n_layers; p.skip_mask = desc->skip_mask;
+  p.n_freqs_pos = desc->n_freqs_pos; p.n_freqs_dir = desc->n_freqs_dir;
+  p.status = a.status;
+  k.net = p;
+  k.a = a;
+  k.cam_hw = (float)(a.cam_W * 0.5);
+  k.cam_hh = (float)(a.cam_H * 0.5);
+  k.cam_f = (float)a.cam_focal;
+  k.use_vis = (a.early_stop_eps > 0.f || a.alpha_thre > 0.f) ? 1 : 0;
+  const int cus = fsn_device_cus();
+  if (cus <= 0) return FSN_E_HIP;
+  hipStream_t s = as_stream(stream);
+  FSN_HIP(hipMemsetAsync(a.work_counter, 0, sizeof(unsigned long long), s));
+  const int key = (desc->d_hidden == 256 ? 4 : 0) + prec;
+  switch (key) {
+    case 0: return launch_occ<4, 0>(k, cus, s);
+    case 1: return launch_occ<4, 1>(k, cus, s);
+    case 2: return launch_occ<4, 2>(k, cus, s);
+    case 3: return launch_occ<4, 3>(k, cus, s);
+    case 4: return launch_occ<8, 0>(k, cus, s);
+    case 5: return launch_occ<8, 1>(k, cus, s);
+    case 6: return launch_occ<8, 2>(k, cus, s);
+    default: return launch_occ<8, 3>(k, cus, s);
+  }
+}

@@ -606,6 +606,79 @@ def occgrid_march(rays_o: Tensor, rays_d: Tensor, aabb: Sequence[float], res: in
     return ri, t0, t1, counts
 
 
+_work_counters: Dict[torch.device, Tensor] = {}
+
+
+def render_occ_fused(pm: PackedMLP, rays_o: Optional[Tensor], rays_d: Optional[Tensor], *, aabb: Sequence[float], res: int,
+                     levels: int, bits: Tensor, near_plane: float, far_plane: float, step: float, max_steps: int,
+                     u: Optional[Tensor] = None, early_stop_eps: float = 1e-4, alpha_thre: float = 0.0,
+                     bkgd=(0.0, 0.0, 0.0), pos_mask: Optional[Tensor] = None, dir_mask: Optional[Tensor] = None,
+                     camera=None, want_counts: bool = False):
+    """render_rays with the occupancy estimator in ONE launch (fsn_render_rays_occgrid): grid march -> density pass ->
+    visibility cull -> full pass -> packed integration, no host sync.  -> colors [R,3], opacity [R,1], depth [R,1],
+    counts {"n_cand", "n_kept"} (int32 [R]) when asked for.  `camera` as in render_fused."""
+    if camera is not None:
+        pose, cH, cW, cfocal, crow0, cnrows, dev = camera
+        dev = torch.device(dev)
+        R = int(cnrows) * int(cW)
+        o = d = None
+    else:
+        o, d = _f32(rays_o, "rays_o").reshape(-1, 3), _f32(rays_d, "rays_d").reshape(-1, 3)
+        R = o.shape[0]
+        dev = o.device
+    a = L.OccRenderArgs()
+    a.R = R
+    keep = [o, d]
+    if camera is None:
+        a.rays_o, a.rays_d = o.data_ptr(), d.data_ptr()
+    else:
+        pmx = pose.detach().to("cpu", torch.float32)[:3, :4].contiguous().reshape(-1).tolist()
+        for i in range(12):
+            a.cam_pose[i] = pmx[i]
+        a.cam_H, a.cam_W, a.cam_row0, a.cam_focal = int(cH), int(cW), int(crow0), float(cfocal)
+    for i in range(6):
+        a.aabb[i] = float(aabb[i])
+    a.res, a.levels, a.bits = int(res), int(levels), bits.data_ptr()
+    a.near_plane, a.far_plane, a.step, a.max_steps = float(near_plane), float(far_plane), float(step), int(max_steps)
+    if u is not None:
+        u = _f32(u, "u").reshape(-1)
+        if u.numel() != R:
+            raise ValueError("u must hold one value per ray")
+        keep.append(u)
+        a.u = u.data_ptr()
+    a.early_stop_eps, a.alpha_thre = float(early_stop_eps), float(alpha_thre)
+    for name, m in (("pos_mask", pos_mask), ("dir_mask", dir_mask)):
+        if m is not None:
+            m = _f32(m, name)
+            keep.append(m)
+            setattr(a, name, m.data_ptr())
+    for i in range(3):
+        a.bkgd[i] = float(bkgd[i])
+    colors = torch.empty(R, 3, device=dev)
+    opacity = torch.empty(R, 1, device=dev)
+    depth = torch.empty(R, 1, device=dev)
+    a.colors, a.opacity, a.depth = colors.data_ptr(), opacity.data_ptr(), depth.data_ptr()
+    counts = {}
+    if want_counts:
+        counts = {"n_cand": torch.zeros(R, dtype=torch.int32, device=dev), "n_kept": torch.zeros(R, dtype=torch.int32, device=dev)}
+        a.n_cand, a.n_kept = counts["n_cand"].data_ptr(), counts["n_kept"].data_ptr()
+    wc = _work_counters.get(dev)
+    if wc is None:
+        wc = _work_counters[dev] = torch.zeros(1, dtype=torch.int64, device=dev)
+    a.work_counter = wc.data_ptr()
+    a.status = status_word(dev).data_ptr()
+    with torch.cuda.device(dev):
+        if launch_timer is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        L.check(L.lib().fsn_render_rays_occgrid(C.byref(pm.desc), pm.prec, _p(pm.blob), C.byref(a), _stream()),
+                "fsn_render_rays_occgrid")
+        if launch_timer is not None:
+            e1.record()
+            launch_timer.append((e0, e1))
+    return colors, opacity, depth, counts
+
+
 def packed_visibility(sigmas: Tensor, t_starts: Tensor, t_ends: Tensor, ray_indices: Tensor, n_rays: int,
                       early_stop_eps: float, alpha_thre: float) -> Tensor:
     sig, t0, t1 = _f32(sigmas, "sigmas").reshape(-1), _f32(t_starts, "t_starts"), _f32(t_ends, "t_ends")

@@ -47,6 +47,12 @@ class OccGridEstimator(nn.Module):
         h = [(self.aabb[3 + a] - self.aabb[a]) / 2.0 * 2 ** lvl for a in range(3)]
         return [c[a] - h[a] for a in range(3)], [c[a] + h[a] for a in range(3)]
 
+    def max_steps(self, render_step_size: float) -> int:
+        """Lattice points a ray can have inside the outermost box (its diagonal / step, + 2)."""
+        lo, hi = self.level_aabb(self.levels - 1)
+        diag = math.sqrt(sum((hi[a] - lo[a]) ** 2 for a in range(3)))
+        return int(min(16384, math.ceil(diag / render_step_size) + 2))
+
     # -- reference surface ---------------------------------------------------------
     @torch.no_grad()
     def sampling(self, rays_o: Tensor, rays_d: Tensor, sigma_fn: Optional[Callable] = None,
@@ -60,9 +66,7 @@ class OccGridEstimator(nn.Module):
         R = rays_o.shape[0]
         if u is None and stratified:
             u = torch.rand(R, device=rays_o.device, generator=self.generator)
-        lo, hi = self.level_aabb(self.levels - 1)
-        diag = math.sqrt(sum((hi[a] - lo[a]) ** 2 for a in range(3)))
-        max_steps = int(min(16384, math.ceil(diag / render_step_size) + 2))
+        max_steps = self.max_steps(render_step_size)
         ri, t0, t1, _ = ops.occgrid_march(rays_o, rays_d, self.aabb, self.resolution, self.levels, self.bits, near_plane,
                                           far_plane, render_step_size, u, max_steps)
         if sigma_fn is not None and (early_stop_eps > 0.0 or alpha_thre > 0.0) and ri.numel() > 0:

@@ -23,6 +23,9 @@ from torch import Tensor, nn
 from .. import ops
 from ..core.models import NeRF
 from ..utils import utilities as U
+from .occgrid import OccGridEstimator
+
+FUSED_OCC_MAX_STEPS = 2048  # csrc/render_occ.hip: samples of one ray group in LDS
 
 
 class StratifiedEstimator(nn.Module):
@@ -167,6 +170,48 @@ def _fused_launch(rays_o, rays_d, camera, estimator, model, model_fine, train, b
     return out
 
 
+def _occ_fusable(estimator, model, model_fine, render_step_size: float) -> bool:
+    return isinstance(estimator, OccGridEstimator) and isinstance(model, NeRF) and model_fine is None and \
+        model.precision in ("fp16x3", "bf16x3", "fp16", "bf16") and estimator.max_steps(render_step_size) <= FUSED_OCC_MAX_STEPS
+
+
+def _fused_occ_launch(rays_o, rays_d, camera, estimator: OccGridEstimator, model: NeRF, train: bool, bk: float,
+                      render_step_size: float, want_counts: bool = False):
+    """The reference's own render path (occupancy estimator in the slot, rendering.py:58-107) as ONE launch
+    (ops.render_occ_fused: march -> density pass -> visibility -> full pass -> packed integration, no host sync),
+    with the fp16 range guard of _fused_launch.  estimator.sampling's defaults: near_plane 0, far_plane 1e10,
+    early_stop_eps 1e-4, alpha_thre 0; `train` = stratified jitter (one value per ray)."""
+    if camera is not None:
+        R, dev = int(camera[5]) * int(camera[2]), torch.device(camera[6])
+    else:
+        R, dev = rays_o.shape[0], rays_o.device
+    u = torch.rand(R, device=dev, generator=estimator.generator) if train else None
+    pm, dm = model._mask(model.pos_mask, dev), model._mask(model.dir_mask, dev)
+
+    def launch():
+        return ops.render_occ_fused(model.packed(), rays_o, rays_d, aabb=estimator.aabb, res=estimator.resolution,
+                                    levels=estimator.levels, bits=estimator.bits, near_plane=0.0, far_plane=1e10,
+                                    step=render_step_size, max_steps=estimator.max_steps(render_step_size), u=u,
+                                    early_stop_eps=1e-4, alpha_thre=0.0, bkgd=(bk, bk, bk), pos_mask=pm, dir_mask=dm,
+                                    camera=camera, want_counts=want_counts)
+
+    guarded = model.range_check and model.fp16_family(model.PRECISIONS[model.precision])
+    if guarded and model.range_check == "deferred":
+        bits = ops.range_poll(dev)
+        if bits:
+            model.fall_back("an EARLIER render_rays call (deferred range check: its outputs are invalid)", bits)
+        out = launch()
+        if model.fp16_family(model.PRECISIONS[model.precision]):
+            ops.range_post(dev)
+        return out
+    out = launch()
+    bits = ops.range_flags(dev) if guarded else 0
+    if bits:
+        model.fall_back("render_rays", bits)
+        out = launch()
+    return out
+
+
 def render_rays(rays_o: Tensor, rays_d: Tensor, estimator, model: nn.Module, train: bool = False,
                 white_bkgd: bool = False, render_step_size: float = 5e-3,
                 device: torch.device = torch.device("cuda"), *, model_fine: Optional[nn.Module] = None,
@@ -185,6 +230,10 @@ def render_rays(rays_o: Tensor, rays_d: Tensor, estimator, model: nn.Module, tra
     # each differentiable where the reference's is
     fused = isinstance(estimator, StratifiedEstimator) and isinstance(model, NeRF) and \
         (model_fine is None or isinstance(model_fine, NeRF)) and not needs_grad
+    if not needs_grad and not want_extras and _occ_fusable(estimator, model, model_fine, render_step_size):
+        # frame rendering with the occupancy estimator (only rgb / depth are consumed, rendering.py:169-171): one launch
+        rgb, opacity, depth, _ = _fused_occ_launch(rays_o, rays_d, None, estimator, model, train, bk, render_step_size)
+        return (rgb, opacity, depth, {}), None, None
     if fused:
         rgb, opacity, depth, ex = _fused_launch(rays_o, rays_d, None, estimator, model, model_fine, train, bk, u, u_fine,
                                                 want_extras)
@@ -264,6 +313,17 @@ def render_frame(hwf: Tuple[int, int, float], near: float, far: float, pose: Ten
         if _deferred_frame_flagged(model, fine, dev):  # (deferred range check: one look per frame)
             rgb, _, depth, _ = _fused_launch(None, None, (pose, H, W, focal, 0, H, dev), estimator, model, model_fine,
                                              train, float(white_bkgd), None, None, False)
+        return rgb.reshape(H, W, 3), depth.clamp(near, far).reshape(H, W)
+    no_grad = not (torch.is_grad_enabled() and isinstance(fine, nn.Module) and fine.training)
+    if no_grad and not ndc and _occ_fusable(estimator, model, model_fine, render_step_size):
+        # the reference's own frame path (occupancy estimator): ONE launch, rays generated inside it
+        dev = torch.device(device)
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        cam = (pose, H, W, focal, 0, H, dev)
+        rgb, _, depth, _ = _fused_occ_launch(None, None, cam, estimator, model, train, float(white_bkgd), render_step_size)
+        if _deferred_frame_flagged(model, model, dev):
+            rgb, _, depth, _ = _fused_occ_launch(None, None, cam, estimator, model, train, float(white_bkgd), render_step_size)
         return rgb.reshape(H, W, 3), depth.clamp(near, far).reshape(H, W)
     rays_o, rays_d = U.get_rays(pose, hwf, device)
     rays_o, rays_d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)

@@ -193,6 +193,49 @@ int fsn_render_rays_fused(const fsn_mlp_desc* desc, int prec, const void* blob_c
                           const void* blob_fine, const fsn_render_args* args_host,
                           fsn_stream_t stream);
 
+/* ---- a6 with the occupancy estimator in the `estimator` slot: the path the reference itself renders with
+ * (render_rays, src/render/rendering.py:58-107; OccGridEstimator, src/run-nerf.py:96-98, 288-295) in ONE launch:
+ * grid march -> density pass (sigma_fn) -> visibility cull -> full pass (rgb_sigma_fn) -> packed volume integration,
+ * per batch of rays inside persistent workgroups, no host sync for the data-dependent sample count.  Same sampling
+ * rule and arithmetic as fsn_occgrid_march + fsn_mlp_fwd + fsn_packed_visibility + fsn_mlp_fwd +
+ * fsn_composite_packed_fwd (the results are the unfused sequence's).  Outputs per ray only: colors [R,3], opacity [R],
+ * depth [R] (what render_frame consumes, rendering.py:169-171), optional sample counts per ray n_cand / n_kept [R]
+ * (int32; NULL to skip).  A caller that needs the packed per-sample extras uses the unfused entry points.
+ *   aabb / res / levels / bits / near_plane / far_plane / step / u (one jitter value per ray or NULL) / max_steps as
+ *   fsn_occgrid_march (max_steps <= 2048 here, else FSN_E_UNSUPPORTED); early_stop_eps / alpha_thre as
+ *   fsn_packed_visibility (both <= 0: no density pass, every marched sample is kept);
+ *   rays_o / rays_d [R,3], or rays_o == NULL and the cam_* fields as in fsn_render_args;
+ *   work_counter: 8 bytes of DEVICE scratch (the launch zeroes it: the global ray-chunk queue);
+ *   prec: FSN_PREC_BF16X3 .. FSN_PREC_FP16. */
+typedef struct fsn_occ_render_args {
+  const float* rays_o;
+  const float* rays_d;
+  int64_t R;
+  float aabb[6];
+  int32_t res, levels;
+  const uint32_t* bits;
+  float near_plane, far_plane, step;
+  const float* u;
+  int32_t max_steps;
+  float early_stop_eps, alpha_thre;
+  const float* pos_mask;
+  const float* dir_mask;
+  float bkgd[3];
+  float* colors;
+  float* opacity;
+  float* depth;
+  int32_t* n_cand;
+  int32_t* n_kept;
+  uint32_t* status;
+  void* work_counter;
+  float cam_pose[12];
+  int32_t cam_H, cam_W, cam_row0;
+  double cam_focal;
+} fsn_occ_render_args;
+
+int fsn_render_rays_occgrid(const fsn_mlp_desc* desc, int prec, const void* blob, const fsn_occ_render_args* args_host,
+                            fsn_stream_t stream);
+
 /* ---- "next" rows ------------------------------------------------------------------ */
 
 /* f4: OcclusionRegularizer.__call__(sigmas, t_vals, ray_idxs)          src/core/loss.py:26-60

@@ -1,0 +1,157 @@
+"""The reference's own render path - occupancy estimator in the `estimator` slot (src/render/rendering.py:58-107,
+src/run-nerf.py:96-98, 288-295) - as ONE launch (csrc/render_occ.hip, VERDICT r2 missing #1): grid march -> density
+pass -> visibility cull -> full pass -> packed integration per batch of rays inside persistent workgroups, no host sync.
+The fused launch must be the unfused sequence (fsn_occgrid_march, fsn_mlp_fwd, fsn_packed_visibility, fsn_mlp_fwd,
+fsn_composite_packed_fwd - itself checked against the oracle in test_occgrid.py / test_trained_parity.py) bit for
+bit: same sampling rule, every sample evaluated independently of its tile position, every ray integrated by one wave
+with the same arithmetic - whatever the batches look like (rays carried over, empty rays, ragged ends)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fsnerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+AABB = [-1.5, -1.5, -1.5, 1.5, 1.5, 1.5]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import fs_nerf_amd  # noqa: F401
+    return torch.device("cuda:0")
+
+
+def make_model(L, D, seed, dev, precision="fp16x3", gain=64.0, shift=3.0):
+    from fs_nerf_amd.core.models import NeRF
+    sd = O.init_nerf_state_dict(L, D, [4], 10, 4, seed=seed)
+    sd["sigma.weight"] *= gain
+    sd["sigma.bias"] += shift
+    m = NeRF(3, 3, L, D, (4,), precision=precision, pos_fn={"n_freqs": 10, "log_space": True},
+             dir_fn={"n_freqs": 4, "log_space": True})
+    m.load_state_dict(sd)
+    return m.to(dev).eval()
+
+
+def sphere_grid(res, levels, dev, radius=0.9):
+    from fs_nerf_amd.render.occgrid import OccGridEstimator
+    est = OccGridEstimator(roi_aabb=torch.tensor(AABB), resolution=res, levels=levels).to(dev)
+    b = torch.zeros(levels, res, res, res, dtype=torch.bool)
+    for lvl in range(levels):
+        ax = (torch.arange(res) + 0.5) / res * 3.0 * 2 ** lvl - 1.5 * 2 ** lvl
+        x, y, z = torch.meshgrid(ax, ax, ax, indexing="ij")
+        b[lvl] = (x * x + y * y + z * z).sqrt() < radius * (1.0 + 0.5 * lvl)
+    est.set_binaries(b)
+    return est.eval()
+
+
+def orbit_rays(n, seed, hw=64):
+    gen = torch.Generator().manual_seed(seed)
+    o, d = O.get_rays(O.pose_from_spherical(4.0311289, 50.0, float(torch.rand(1, generator=gen)) * 360.0), (hw, hw, hw * 1.39))
+    idx = torch.randperm(hw * hw, generator=gen)[:n]
+    return o.reshape(-1, 3)[idx].contiguous(), d.reshape(-1, 3)[idx].contiguous()
+
+
+def both_paths(o, d, est, m, dev, step, train=False, white=True):
+    from fs_nerf_amd.render import rendering as Rm
+    with torch.no_grad():
+        if train:
+            est.generator = torch.Generator(device=dev).manual_seed(77)
+        (rgb_u, op_u, dep_u, ex), ri, tv = Rm.render_rays(o, d, est, m, train=train, white_bkgd=white, render_step_size=step, device=dev)
+        if train:
+            est.generator = torch.Generator(device=dev).manual_seed(77)
+        (rgb_f, op_f, dep_f, _), ri_f, tv_f = Rm.render_rays(o, d, est, m, train=train, white_bkgd=white, render_step_size=step,
+                                                            device=dev, want_extras=False)
+    assert ri_f is None and tv_f is None
+    return (rgb_u, op_u, dep_u, ri), (rgb_f, op_f, dep_f)
+
+
+@pytest.mark.parametrize("net,res,levels,step,train", [((4, 128), 32, 1, 2e-2, False), ((8, 256), 32, 1, 2e-2, False),
+                                                        ((8, 256), 64, 2, 1e-2, True), ((4, 128), 128, 1, 5e-3, True)])
+def test_fused_occupancy_launch_is_the_unfused_sequence(dev, net, res, levels, step, train):
+    from fs_nerf_amd import ops
+    m = make_model(net[0], net[1], 4, dev)
+    est = sphere_grid(res, levels, dev)
+    o, d = orbit_rays(1003, 5)  # not a multiple of the 8-ray chunks
+    (rgb_u, op_u, dep_u, ri), (rgb_f, op_f, dep_f) = both_paths(o, d, est, m, dev, step, train)
+    assert ri.numel() > 0
+    assert torch.equal(rgb_f, rgb_u) and torch.equal(op_f, op_u) and torch.equal(dep_f, dep_u), \
+        f"max |d rgb| {float((rgb_f - rgb_u).abs().max()):.3e}"
+    # sample counts per ray as the launch saw them
+    if train:
+        est.generator = torch.Generator(device=dev).manual_seed(77)
+        u = torch.rand(o.shape[0], device=dev, generator=est.generator)
+    else:
+        u = None
+    _, _, _, cnt = ops.render_occ_fused(m.packed(), o.to(dev), d.to(dev), aabb=est.aabb, res=est.resolution, levels=est.levels,
+                                        bits=est.bits, near_plane=0.0, far_plane=1e10, step=step,
+                                        max_steps=est.max_steps(step), u=u, bkgd=(1.0, 1.0, 1.0), want_counts=True)
+    assert torch.equal(cnt["n_kept"].long(), torch.bincount(ri, minlength=o.shape[0]))
+    assert bool((cnt["n_cand"] >= cnt["n_kept"]).all()) and int(cnt["n_cand"].sum()) > int(cnt["n_kept"].sum()), \
+        "the visibility cull drops samples behind the surface"
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16", "bf16"])
+def test_fused_occupancy_other_precision_modes(dev, precision):
+    m = make_model(8, 256, 4, dev, precision)
+    est = sphere_grid(32, 1, dev)
+    o, d = orbit_rays(700, 6)
+    (rgb_u, op_u, dep_u, ri), (rgb_f, op_f, dep_f) = both_paths(o, d, est, m, dev, 2e-2)
+    if precision == "bf16x3":
+        assert torch.equal(rgb_f, rgb_u) and torch.equal(dep_f, dep_u)
+    else:
+        # single pass: the standalone forward runs two sample groups per wave (256-sample tiles), the fused occupancy
+        # kernel one - the same products summed in the same order, but an independent instruction stream: compared at
+        # the mode's own accuracy (2^-8 / 2^-11 per product) instead of bitwise
+        tol = {"bf16": 2e-3, "fp16": 3e-4}[precision]
+        assert float((rgb_f - rgb_u).abs().max()) <= tol and float((op_f - op_u).abs().max()) <= tol
+
+
+def test_fused_occupancy_batches_carry_and_empty_rays(dev):
+    """Dense grid, small step: ~300 samples per ray, so a batch (2048 samples) holds ~6 rays and almost every chunk of
+    8 is split and carried; a third of the rays miss the box (zero samples: pure background); 20,003 rays keep all 256
+    workgroups pulling from the queue.  Still bit for bit the unfused sequence."""
+    from fs_nerf_amd.render.occgrid import OccGridEstimator
+    m = make_model(4, 128, 9, dev, gain=2.0, shift=1.0)  # thin positive medium: the visibility cull keeps most samples
+    est = OccGridEstimator(roi_aabb=torch.tensor(AABB), resolution=16, levels=1).to(dev)
+    est.set_binaries(torch.ones(1, 16, 16, 16, dtype=torch.bool))
+    est.eval()
+    o, d = orbit_rays(20003, 8, hw=160)
+    miss = torch.arange(o.shape[0]) % 3 == 0
+    d = d.clone()
+    d[miss] = -d[miss]  # looking away from the box
+    (rgb_u, op_u, dep_u, ri), (rgb_f, op_f, dep_f) = both_paths(o, d, est, m, dev, 5e-3)
+    per_ray = torch.bincount(ri, minlength=o.shape[0]).cpu()
+    assert int(per_ray[miss].max()) == 0 and float(per_ray[~miss].float().mean()) > 150
+    assert torch.equal(rgb_f, rgb_u) and torch.equal(op_f, op_u) and torch.equal(dep_f, dep_u)
+    assert bool((rgb_f[miss.to(dev)] == 1.0).all()) and float(dep_f[miss.to(dev)].abs().max()) == 0.0
+    # an empty grid: background everywhere, no MLP tile at all
+    est.set_binaries(torch.zeros(1, 16, 16, 16, dtype=torch.bool))
+    (rgb_u, op_u, dep_u, ri), (rgb_f, op_f, dep_f) = both_paths(o[:100], d[:100], est, m, dev, 5e-3)
+    assert ri.numel() == 0 and bool((rgb_f == 1.0).all()) and float(op_f.abs().max()) == 0.0
+
+
+def test_fused_occupancy_frame_is_one_launch_and_matches_the_ray_path(dev):
+    """render_frame with the occupancy estimator: one launch with the rays generated in it == get_rays tensors through
+    render_rays (fused, chunked) == the unfused sequence."""
+    from fs_nerf_amd import ops
+    from fs_nerf_amd.render import rendering as Rm
+    from fs_nerf_amd.utils import utilities as U
+    m = make_model(8, 256, 4, dev)
+    est = sphere_grid(64, 1, dev)
+    pose = O.pose_from_spherical(4.0311289, 50.0, 123.0)
+    hwf = (90, 121, 150.0)
+    step = 1e-2
+    timer = ops.launch_timer = []
+    with torch.no_grad():
+        img, depth = Rm.render_frame(hwf, 2.0, 6.0, pose, 4096, est, m, white_bkgd=True, render_step_size=step, device=dev)
+    ops.launch_timer = None
+    assert len(timer) == 1, "one launch per frame"
+    o, d = U.get_rays(pose, hwf, dev)
+    o, d = o.reshape(-1, 3), d.reshape(-1, 3)
+    with torch.no_grad():
+        (rgb_f, _, dep_f, _), _, _ = Rm.render_rays(o, d, est, m, white_bkgd=True, render_step_size=step, device=dev, want_extras=False)
+        (rgb_u, _, dep_u, _), ri, _ = Rm.render_rays(o, d, est, m, white_bkgd=True, render_step_size=step, device=dev)
+    assert torch.equal(img.reshape(-1, 3), rgb_f) and torch.equal(rgb_f, rgb_u)
+    assert torch.equal(depth.reshape(-1), dep_u.reshape(-1).clamp(2.0, 6.0))
+    assert 0.05 < float((torch.bincount(ri, minlength=o.shape[0]) > 0).float().mean()) < 0.95, "part of the frame is empty space"
