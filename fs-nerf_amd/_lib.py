@@ -70,6 +70,7 @@ SIGNATURES = {
     "fsn_mlp_pack": (_i, [_PD, _i, _vp, _vp, _vp, _vp]),
     "fsn_mlp_pack_host": (_i, [_PD, _i, _vp, _vp, _vp]),
     "fsn_mlp_fwd": (_i, [_PD, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "fsn_mlp_fwd_rays": (_i, [_PD, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i64, _vp, _vp, _vp]),
     "fsn_render_rays_fused": (_i, [_PD, _i, _vp, _vp, C.POINTER(RenderArgs), _vp]),
     "fsn_render_rays_occgrid": (_i, [_PD, _i, _vp, C.POINTER(OccRenderArgs), _vp]),
     "fsn_occlusion_reg_fwd": (_i, [_vp, _vp, _vp, _i64, _i64, _f, _f, _i, _vp, _vp, _vp]),
@@ -78,6 +79,7 @@ SIGNATURES = {
     "fsn_depth_colormap": (_i, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "fsn_nerf_train_workspace_floats": (_i64, [_PD, _i, _i64]),
     "fsn_nerf_train_fwd": (_i, [_PD, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "fsn_nerf_train_fwd_rays": (_i, [_PD, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "fsn_nerf_train_bwd": (_i, [_PD, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fsn_occlusion_reg_bwd": (_i, [_vp, _i64, _vp, _i64, _f, _f, _i, _vp, _vp, _vp, _vp]),
     "fsn_occgrid_march": (_i, [_vp, _vp, _i64, _vp, _i, _i, _vp, _f, _f, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -56,21 +56,28 @@ class _NerfTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, x, dirs, *params):
+        """`x` / `dirs` [..., 3] tensors, or - ray form - x = (rays_o, rays_d, ray_indices, t_starts, t_ends), dirs = None:
+        the samples are the midpoints of the packed intervals, formed inside the launch (no gathered [N,3] tensors)."""
         n = len(params) // 2
         weights, biases = params[:n], params[n:]
         desc = ops.make_desc(model.n_layers, model.d_hidden, model.skip, model.pos_encoder.freqs,
                              model.dir_encoder.freqs)
-        dev = x.device
+        ray_form = isinstance(x, tuple)
+        dev = x[0].device if ray_form else x.device
         prec = model.train_prec()
         # range-guard word of THIS call (one network, one step): the kernels of its forward and backward report into
         # it, and only they consult it - a flag raised by another network or by an inference launch must not zero
         # this network's gradients (the sticky per-device word of the inference path is not used here)
         word = torch.zeros(1, dtype=torch.int32, device=dev) if model.fp16_family(prec) else None
-        out, work = ops.nerf_train_fwd(desc, prec, weights, biases, x, dirs, model._mask(model.pos_mask, dev),
-                                       model._mask(model.dir_mask, dev), status=word)
+        if ray_form:
+            out, work = ops.nerf_train_fwd_rays(desc, prec, weights, biases, *x, model._mask(model.pos_mask, dev),
+                                                model._mask(model.dir_mask, dev), status=word)
+        else:
+            out, work = ops.nerf_train_fwd(desc, prec, weights, biases, x, dirs, model._mask(model.pos_mask, dev),
+                                           model._mask(model.dir_mask, dev), status=word)
         ctx.desc, ctx.prec, ctx.work, ctx.out, ctx.model, ctx.word = desc, prec, work, out, model, word
         ctx.weights = [w.detach() for w in weights]
-        return out.reshape(*x.shape[:-1], 4)
+        return out if ray_form else out.reshape(*x.shape[:-1], 4)
 
     @staticmethod
     def backward(ctx, d_out):
@@ -207,6 +214,24 @@ class NeRF(nn.Module):
 
     def _mask(self, m: Optional[Tensor], dev) -> Optional[Tensor]:
         return None if m is None else m.to(dev, torch.float32)
+
+    def forward_rays(self, rays_o: Tensor, rays_d: Tensor, ray_indices: Tensor, t_starts: Tensor, t_ends: Tensor,
+                     full: bool = True) -> Tensor:
+        """`self(x, d)` (full) or `self(x)` (density only) on the midpoints of packed intervals - what the reference's
+        closures compute as `to = rays_o[ri]; td = rays_d[ri]; x = to + td * (t0 + t1)[:, None] / 2; model(x, td)`
+        (rendering.py:58-64, 76-84) - with the gathers and the midpoint arithmetic inside the launch: no [N,3] tensor
+        is materialised.  Same values bit for bit; gradients (training mode, full pass) flow to the parameters."""
+        if full and self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            ws, bs = self._tensors()
+            return _NerfTrainFn.apply(self, (rays_o, rays_d, ray_indices, t_starts, t_ends), None, *ws, *bs)
+        dev = rays_o.device
+        args = (rays_o, rays_d, ray_indices, t_starts, t_ends, full, self._mask(self.pos_mask, dev), self._mask(self.dir_mask, dev))
+        out = ops.mlp_fwd_rays(self.packed(), *args)
+        bits = ops.range_flags(dev) if self.range_check is True and self.fp16_family(self.PRECISIONS[self.precision]) else 0
+        if bits:
+            self.fall_back("NeRF.forward_rays", bits)
+            out = ops.mlp_fwd_rays(self.packed(), *args)
+        return out
 
     # -- reference surface ---------------------------------------------------------
     def forward(self, x: Tensor, dirs: Optional[Tensor] = None) -> Tensor:

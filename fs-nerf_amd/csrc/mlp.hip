@@ -67,7 +67,26 @@ struct MlpFwdArgs {
   const float* dir_mask;
   int64_t n;
   float* out;
+  // ray form (fsn_mlp_fwd_rays): sample s is the midpoint of [t0[s], t1[s]) on ray ri[s]; x / dirs are not read
+  const float *rays_o, *rays_d, *t0, *t1;
+  const int64_t* ri;
+  int32_t full;
 };
+
+// sample s of the ray form: x = o + d (t0 + t1) / 2 in the reference's operation order (rendering.py:59-61, 77-79:
+// to + td * (t_starts + t_ends)[:, None] / 2.0), dirs = d
+__device__ __forceinline__ void ray_sample(const float* __restrict__ ro, const float* __restrict__ rd,
+                                           const int64_t* __restrict__ ri, const float* __restrict__ t0,
+                                           const float* __restrict__ t1, int64_t s, float* q, bool with_dir) {
+  const int64_t r = ri[s];
+  const float tm = t0[s] + t1[s];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float dc = rd[3 * r + c];
+    q[c] = ro[3 * r + c] + dc * tm / 2.0f;
+    if (with_dir) q[3 + c] = dc;
+  }
+}
 
 // sample source of the standalone kernel: the tile's positions / directions staged in LDS
 struct TileSrc {
@@ -105,8 +124,12 @@ __global__ __launch_bounds__(kThreads) void k_mlp_fwd(MlpFwdArgs a) {
       const int64_t s = tile * TILE + wave * (16 * NG) + lane;
       const int64_t sc = s < a.n ? s : a.n - 1;
       float* q = in_lds + (wave * (16 * NG) + lane) * 6;
-      q[0] = a.x[3 * sc]; q[1] = a.x[3 * sc + 1]; q[2] = a.x[3 * sc + 2];
-      if (full) { q[3] = a.dirs[3 * sc]; q[4] = a.dirs[3 * sc + 1]; q[5] = a.dirs[3 * sc + 2]; }
+      if (a.ri) {
+        ray_sample(a.rays_o, a.rays_d, a.ri, a.t0, a.t1, sc, q, full);
+      } else {
+        q[0] = a.x[3 * sc]; q[1] = a.x[3 * sc + 1]; q[2] = a.x[3 * sc + 2];
+        if (full) { q[3] = a.dirs[3 * sc]; q[4] = a.dirs[3 * sc + 1]; q[5] = a.dirs[3 * sc + 2]; }
+      }
     }
     __builtin_amdgcn_wave_barrier();
     const int64_t s = tile * TILE + wave * (16 * NG) + (lane & 15);
@@ -148,7 +171,7 @@ static int launch_mlp_fwd(const MlpFwdArgs& a, int cus, hipStream_t s) {
   constexpr int TILE = 128 * groups_per_wave<NT, PREC>();
   const int64_t ntiles = (a.n + TILE - 1) / TILE;
   const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
-  if (a.dirs) k_mlp_fwd<NT, PREC, true><<<grid, kThreads, 0, s>>>(a);
+  if (a.dirs || (a.ri && a.full)) k_mlp_fwd<NT, PREC, true><<<grid, kThreads, 0, s>>>(a);
   else k_mlp_fwd<NT, PREC, false><<<grid, kThreads, 0, s>>>(a);
   FSN_LAUNCH_CHECK("k_mlp_fwd");
   return FSN_OK;
@@ -191,20 +214,19 @@ extern "C" int fsn_mlp_pack_host(const fsn_mlp_desc* desc, int prec, const float
   return FSN_OK;
 }
 
-extern "C" int fsn_mlp_fwd(const fsn_mlp_desc* desc, int prec, const void* blob, const float* x, const float* dirs,
-                           const float* pos_mask, const float* dir_mask, int64_t n, float* out, uint32_t* status,
-                           fsn_stream_t stream) {
-  FSN_REQUIRE(desc && n >= 0, FSN_E_INVALID, "fsn_mlp_fwd: bad arguments");
+static int mlp_fwd_any(const char* who, const fsn_mlp_desc* desc, int prec, const void* blob, MlpFwdArgs a, uint32_t* status,
+                       fsn_stream_t stream) {
+  FSN_REQUIRE(desc && a.n >= 0, FSN_E_INVALID, "%s: bad arguments", who);
   NetGeom G;
   const char* why;
   const int rc = build_geom(*desc, prec, G, &why);
-  FSN_REQUIRE(rc == FSN_OK, rc, "fsn_mlp_fwd: %s", why);
-  if (n == 0) return FSN_OK;
-  FSN_REQUIRE(blob && x && out, FSN_E_INVALID, "fsn_mlp_fwd: null pointer");
-  FSN_REQUIRE(G.aux_floats <= kAuxCapFloats, FSN_E_UNSUPPORTED, "fsn_mlp_fwd: network too deep for the LDS aux area");
+  FSN_REQUIRE(rc == FSN_OK, rc, "%s: %s", who, why);
+  if (a.n == 0) return FSN_OK;
+  FSN_REQUIRE(blob && a.out && (a.x || (a.ri && a.rays_o && a.rays_d && a.t0 && a.t1)), FSN_E_INVALID, "%s: null pointer", who);
+  FSN_REQUIRE(G.aux_floats <= kAuxCapFloats, FSN_E_UNSUPPORTED, "%s: network too deep for the LDS aux area", who);
   const int cus = fsn_device_cus();
   if (cus <= 0) return FSN_E_HIP;
-  MlpFwdArgs a{make_net_params(*desc, G, blob, status), x, dirs, pos_mask, dir_mask, n, out};
+  a.net = make_net_params(*desc, G, blob, status);
   hipStream_t s = as_stream(stream);
   if (prec == FSN_PREC_FP16X2) return desc->d_hidden == 256 ? launch_mlp_fwd<8, 6>(a, cus, s) : launch_mlp_fwd<4, 6>(a, cus, s);
   const int key = (desc->d_hidden == 256 ? 4 : 0) + prec;
@@ -218,4 +240,22 @@ extern "C" int fsn_mlp_fwd(const fsn_mlp_desc* desc, int prec, const void* blob,
     case 6: return launch_mlp_fwd<8, 2>(a, cus, s);
     default: return launch_mlp_fwd<8, 3>(a, cus, s);
   }
+}
+
+extern "C" int fsn_mlp_fwd(const fsn_mlp_desc* desc, int prec, const void* blob, const float* x, const float* dirs,
+                           const float* pos_mask, const float* dir_mask, int64_t n, float* out, uint32_t* status,
+                           fsn_stream_t stream) {
+  MlpFwdArgs a{};
+  a.x = x; a.dirs = dirs; a.pos_mask = pos_mask; a.dir_mask = dir_mask; a.n = n; a.out = out;
+  return mlp_fwd_any("fsn_mlp_fwd", desc, prec, blob, a, status, stream);
+}
+
+extern "C" int fsn_mlp_fwd_rays(const fsn_mlp_desc* desc, int prec, const void* blob, const float* rays_o,
+                                const float* rays_d, const int64_t* ray_indices, const float* t_starts,
+                                const float* t_ends, int full, const float* pos_mask, const float* dir_mask, int64_t n,
+                                float* out, uint32_t* status, fsn_stream_t stream) {
+  MlpFwdArgs a{};
+  a.rays_o = rays_o; a.rays_d = rays_d; a.ri = ray_indices; a.t0 = t_starts; a.t1 = t_ends; a.full = full ? 1 : 0;
+  a.pos_mask = pos_mask; a.dir_mask = dir_mask; a.n = n; a.out = out;
+  return mlp_fwd_any("fsn_mlp_fwd_rays", desc, prec, blob, a, status, stream);
 }

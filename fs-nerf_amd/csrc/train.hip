@@ -104,6 +104,22 @@ extern "C" int fsn_nerf_train_fwd(const fsn_mlp_desc* desc, int prec, const floa
   return fused_train_fwd(desc, prec, W, b, x, dirs, pos_mask, dir_mask, n, ws, out, status, as_stream(stream));
 }
 
+extern "C" int fsn_nerf_train_fwd_rays(const fsn_mlp_desc* desc, int prec, const float* const* W, const float* const* b,
+                                       const float* rays_o, const float* rays_d, const int64_t* ray_indices,
+                                       const float* t_starts, const float* t_ends, const float* pos_mask,
+                                       const float* dir_mask, int64_t n, float* ws, float* out, uint32_t* status,
+                                       fsn_stream_t stream) {
+  int rc = check_desc(desc);
+  if (rc != FSN_OK) return rc;
+  FSN_REQUIRE(prec >= 0 && prec <= FSN_PREC_FP16, FSN_E_INVALID, "fsn_nerf_train_fwd_rays: unknown precision");
+  if (n == 0) return FSN_OK;
+  FSN_REQUIRE(W && b && rays_o && rays_d && ray_indices && t_starts && t_ends && ws && out, FSN_E_INVALID,
+              "fsn_nerf_train_fwd_rays: null pointer");
+  FSN_REQUIRE(n < (1ll << 31), FSN_E_UNSUPPORTED, "fsn_nerf_train_fwd_rays: n too large for one call");
+  const TrainRays rays{rays_o, rays_d, t_starts, t_ends, ray_indices};
+  return fused_train_fwd(desc, prec, W, b, nullptr, nullptr, pos_mask, dir_mask, n, ws, out, status, as_stream(stream), &rays);
+}
+
 extern "C" int fsn_nerf_train_bwd(const fsn_mlp_desc* desc, int prec, const float* const* W, int64_t n, float* ws,
                                   const float* out, const float* d_out, const float* grad_scale, float* const* dW,
                                   float* const* db, uint32_t* status, fsn_stream_t stream) {

@@ -181,6 +181,9 @@ struct TrainFwdArgs {
   float* ws;
   int64_t off_h, h_stride, off_bo, off_pe, off_de, off_mask, mask_stride;
   int32_t D;
+  // ray form (fsn_nerf_train_fwd_rays): sample s = midpoint of [t0[s], t1[s]) on ray ri[s] (x / dirs are not read)
+  const float *rays_o, *rays_d, *t0, *t1;
+  const int64_t* ri;
 };
 
 struct TileSrcT {
@@ -210,8 +213,19 @@ __global__ __launch_bounds__(kThreads) void k_train_fwd(TrainFwdArgs a) {
     const int64_t sc = s < a.n ? s : a.n - 1;
     if (lane < 16) {
       float* q = in_lds + col * 6;
-      q[0] = a.x[3 * sc]; q[1] = a.x[3 * sc + 1]; q[2] = a.x[3 * sc + 2];
-      q[3] = a.dirs[3 * sc]; q[4] = a.dirs[3 * sc + 1]; q[5] = a.dirs[3 * sc + 2];
+      if (a.ri) {  // x = o + d (t0 + t1) / 2, the reference's operation order (rendering.py:77-79); dirs = d
+        const int64_t r = a.ri[sc];
+        const float tm = a.t0[sc] + a.t1[sc];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float dc = a.rays_d[3 * r + c];
+          q[c] = a.rays_o[3 * r + c] + dc * tm / 2.0f;
+          q[3 + c] = dc;
+        }
+      } else {
+        q[0] = a.x[3 * sc]; q[1] = a.x[3 * sc + 1]; q[2] = a.x[3 * sc + 2];
+        q[3] = a.dirs[3 * sc]; q[4] = a.dirs[3 * sc + 1]; q[5] = a.dirs[3 * sc + 2];
+      }
     }
     __builtin_amdgcn_wave_barrier();
     const TileSrcT src{in_lds + col * 6};
@@ -635,7 +649,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_wgrad(WgArgs a) {  // (2 waves p
             acc[ti][bt] = mfma32<F16>(af[ti][ks].hi, bh, acc[ti][bt]);
             if (X3) {
               acc[ti][bt] = mfma32<F16>(af[ti][ks].lo, bh, acc[ti][bt]);
+#ifndef FSN_WGRAD_NOBLO  // experiment: drop the (dPre high) x (input low) product
               acc[ti][bt] = mfma32<F16>(af[ti][ks].hi, bl, acc[ti][bt]);
+#endif
             }
           }
         }
@@ -882,7 +898,7 @@ static int launch_wgrad(int prec, const WgArgs& a, int njobs, hipStream_t s) {
 
 int fused_train_fwd(const fsn_mlp_desc* d, int prec, const float* const* W, const float* const* b, const float* x,
                     const float* dirs, const float* pos_mask, const float* dir_mask, int64_t n, float* ws, float* out,
-                    uint32_t* status, hipStream_t s) {
+                    uint32_t* status, hipStream_t s, const TrainRays* rays) {
   FusedLayout F;
   const char* why;
   int rc = make_fused_layout(*d, prec, n, F, &why);
@@ -896,7 +912,8 @@ int fused_train_fwd(const fsn_mlp_desc* d, int prec, const float* const* W, cons
   const int cus = fsn_device_cus();
   if (cus <= 0) return FSN_E_HIP;
   TrainFwdArgs a{net_params(*d, G, blob, status), x, dirs, pos_mask, dir_mask, n, out, ws, F.h, F.h_stride, F.bo, F.pe, F.de,
-                 F.mask, F.mask_stride, F.D};
+                 F.mask, F.mask_stride, F.D, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (rays) { a.rays_o = rays->rays_o; a.rays_d = rays->rays_d; a.t0 = rays->t0; a.t1 = rays->t1; a.ri = rays->ri; }
   const unsigned grid = (unsigned)(F.T < cus ? F.T : cus);
   const int key = (F.D == 256 ? 4 : 0) + prec;
   switch (key) {

@@ -330,6 +330,23 @@ def mlp_fwd(pm: PackedMLP, x: Tensor, dirs: Optional[Tensor] = None, pos_mask: O
 # stream right around the C-ABI call (the kernel's own duration, without the host path around it)
 launch_timer: Optional[list] = None
 
+def mlp_fwd_rays(pm: PackedMLP, rays_o: Tensor, rays_d: Tensor, ray_indices: Tensor, t_starts: Tensor, t_ends: Tensor,
+                 full: bool, pos_mask: Optional[Tensor] = None, dir_mask: Optional[Tensor] = None) -> Tensor:
+    """NeRF.forward on the midpoints of packed intervals (the reference's sigma_fn / rgb_sigma_fn, rendering.py:58-64,
+    76-84) without materialising the gathered [N,3] positions / directions: -> [N,4] (full) or [N,1]."""
+    o, d = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d")
+    ri, t0, t1 = _i64(ray_indices, "ray_indices"), _f32(t_starts, "t_starts"), _f32(t_ends, "t_ends")
+    n = ri.numel()
+    pmk = None if pos_mask is None else _f32(pos_mask, "pos_mask")
+    dmk = None if dir_mask is None else _f32(dir_mask, "dir_mask")
+    out = torch.empty(n, 4 if full else 1, device=o.device, dtype=torch.float32)
+    with torch.cuda.device(o.device):
+        L.check(L.lib().fsn_mlp_fwd_rays(C.byref(pm.desc), pm.prec, _p(pm.blob), _p(o), _p(d), _p(ri), _p(t0), _p(t1),
+                                         1 if full else 0, _p(pmk), _p(dmk), n, _p(out), _p(status_word(o.device)),
+                                         _stream()), "fsn_mlp_fwd_rays")
+    return out
+
+
 _edges_ws: Dict[Tuple[torch.device, int], Tensor] = {}
 
 
@@ -514,6 +531,29 @@ def video_tensors(frames: Tensor, d_frames: Tensor, cmap: str = "plasma") -> Tup
 # ------------------------------------------------------------------ training step
 def _ptr_array(ts: Sequence[Tensor]):
     return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def nerf_train_fwd_rays(desc: L.MlpDesc, prec: int, weights: Sequence[Tensor], biases: Sequence[Tensor], rays_o: Tensor,
+                        rays_d: Tensor, ray_indices: Tensor, t_starts: Tensor, t_ends: Tensor, pos_mask: Optional[Tensor],
+                        dir_mask: Optional[Tensor], status: Optional[Tensor] = None):
+    """nerf_train_fwd with the samples in ray form (midpoints of packed intervals): -> (out [n,4], workspace)."""
+    o, d = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d")
+    ri, t0, t1 = _i64(ray_indices, "ray_indices"), _f32(t_starts, "t_starts"), _f32(t_ends, "t_ends")
+    n = ri.numel()
+    ws_ = [_f32(w.detach(), "weight") for w in weights]
+    bs_ = [_f32(b.detach(), "bias") for b in biases]
+    with torch.cuda.device(o.device):
+        pm = None if pos_mask is None else _f32(pos_mask, "pos_mask")
+        dm = None if dir_mask is None else _f32(dir_mask, "dir_mask")
+        out = torch.empty(n, 4, device=o.device, dtype=torch.float32)
+        nfl = L.lib().fsn_nerf_train_workspace_floats(C.byref(desc), prec, n)
+        if nfl < 0:
+            L.check(int(nfl), "fsn_nerf_train_workspace_floats")
+        work = torch.empty(max(int(nfl), 1), device=o.device, dtype=torch.float32)
+        L.check(L.lib().fsn_nerf_train_fwd_rays(C.byref(desc), prec, _ptr_array(ws_), _ptr_array(bs_), _p(o), _p(d), _p(ri),
+                                                _p(t0), _p(t1), _p(pm), _p(dm), n, _p(work), _p(out), _p(status), _stream()),
+                "fsn_nerf_train_fwd_rays")
+    return out, work
 
 
 def nerf_train_fwd(desc: L.MlpDesc, prec: int, weights: Sequence[Tensor], biases: Sequence[Tensor], x: Tensor,

@@ -247,6 +247,8 @@ def render_rays(rays_o: Tensor, rays_d: Tensor, estimator, model: nn.Module, tra
         output = (rgb, opacity, depth, ex)
     else:
         def sigma_fn(t_starts, t_ends, ray_indices):
+            if isinstance(model, NeRF):  # same values, gathers and midpoints inside the launch (no [N,3] tensors)
+                return model.forward_rays(rays_o, rays_d, ray_indices, t_starts, t_ends, full=False).squeeze(-1)
             to, td = rays_o[ray_indices], rays_d[ray_indices]
             x = to + td * (t_starts + t_ends)[:, None] / 2.0
             return model(x).squeeze(-1)
@@ -257,6 +259,9 @@ def render_rays(rays_o: Tensor, rays_d: Tensor, estimator, model: nn.Module, tra
         fine = model_fine if model_fine is not None else model
 
         def rgb_sigma_fn(t_starts, t_ends, ray_indices):
+            if isinstance(fine, NeRF):
+                out = fine.forward_rays(rays_o, rays_d, ray_indices, t_starts, t_ends, full=True)
+                return out[..., :3], out[..., -1]
             to, td = rays_o[ray_indices], rays_d[ray_indices]
             x = to + td * (t_starts + t_ends)[:, None] / 2.0
             out = fine(x, td)

@@ -141,6 +141,14 @@ int fsn_mlp_pack_host(const fsn_mlp_desc* desc, int prec, const float* const* we
 int fsn_mlp_fwd(const fsn_mlp_desc* desc, int prec, const void* blob, const float* x,
                 const float* dirs, const float* pos_mask, const float* dir_mask, int64_t n,
                 float* out, uint32_t* status, fsn_stream_t stream);
+/* fsn_mlp_fwd_rays: the same forward with the samples given as the reference's closures form them (sigma_fn /
+ * rgb_sigma_fn, src/render/rendering.py:58-64, 76-84): sample s is the midpoint of [t_starts[s], t_ends[s]) on ray
+ * ray_indices[s], x = o + d (t0 + t1) / 2 evaluated in the launch in the reference's operation order, dirs = d
+ * (full != 0: [n,4] output, else [n,1]) - no [n,3] position / direction tensors in HBM. */
+int fsn_mlp_fwd_rays(const fsn_mlp_desc* desc, int prec, const void* blob, const float* rays_o, const float* rays_d,
+                     const int64_t* ray_indices, const float* t_starts, const float* t_ends, int full,
+                     const float* pos_mask, const float* dir_mask, int64_t n, float* out, uint32_t* status,
+                     fsn_stream_t stream);
 
 /* ---- a6: render_rays(rays_o, rays_d, estimator, model, ...)   src/render/rendering.py:25-107
  * The whole path fused in one launch for the fixed-count sampler: stratified edges ->
@@ -271,6 +279,12 @@ int64_t fsn_nerf_train_workspace_floats(const fsn_mlp_desc* desc, int prec, int6
 int fsn_nerf_train_fwd(const fsn_mlp_desc* desc, int prec, const float* const* weights, const float* const* biases,
                        const float* x, const float* dirs, const float* pos_mask, const float* dir_mask,
                        int64_t n, float* workspace, float* out, uint32_t* status, fsn_stream_t stream);
+/* fsn_nerf_train_fwd with the samples in ray form (as fsn_mlp_fwd_rays): the training step's forward reads the rays and
+ * the packed intervals, never a gathered [n,3] tensor (run-nerf.py:243-252 -> rendering.py:76-84). */
+int fsn_nerf_train_fwd_rays(const fsn_mlp_desc* desc, int prec, const float* const* weights, const float* const* biases,
+                            const float* rays_o, const float* rays_d, const int64_t* ray_indices, const float* t_starts,
+                            const float* t_ends, const float* pos_mask, const float* dir_mask, int64_t n,
+                            float* workspace, float* out, uint32_t* status, fsn_stream_t stream);
 int fsn_nerf_train_bwd(const fsn_mlp_desc* desc, int prec, const float* const* weights, int64_t n, float* workspace,
                        const float* out, const float* d_out, const float* grad_scale, float* const* d_weights,
                        float* const* d_biases, uint32_t* status, fsn_stream_t stream);

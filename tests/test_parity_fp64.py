@@ -445,6 +445,41 @@ def test_config5_single_pass_vs_rounding_emulating_oracle(dev, prec):
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_config5_end_to_end_bound_on_every_output(dev, prec):
+    """configs[4] END TO END - coarse pass, resampling on the kernel's OWN coarse weights, fine pass,
+    integration, nothing handed over - with a bound on weights and depth_map too.  Yardstick: the rounding-emulating
+    oracle evaluated in float64 (operands rounded to the 16-bit format, products and sums exact to double: the
+    arithmetic the mode DEFINES) against the same oracle in float32 (one legitimate float32 evaluation of that
+    definition: its distance from the float64 one is what summation order and the last-bit rounding flips it causes
+    are worth, resampling amplification included).  The kernel is another float32 evaluation (own summation order,
+    hardware sine in the encodings): its error against the float64 emulation must be of that size - max and 99th
+    percentile within 2 x the float32 emulation's (+ the floors of the parity criterion), per output.  (Measured:
+    0.8 - 1.5 x on every output, e.g. bf16 weights 4.1e-4 against 4.2e-4, depth 1.4e-4 against 9.8e-5.)"""
+    from fs_nerf_amd.render import rendering as Rm
+    L, D, R, S, NI = 8, 256, 128, 128, 256
+    o, d, gen = orbit_rays(R, 5, 1600, 2222.2)
+    u, uf = torch.rand(R, generator=gen), torch.rand(R, NI, generator=gen)
+    sd_c, sd_f = make_sd(L, D, 42), make_sd(L, D, 43)
+    mc, mf = hip_model(sd_c, L, D, dev, prec), hip_model(sd_f, L, D, dev, prec)
+    est = Rm.StratifiedEstimator(2.0, 6.0, S, NI)
+    with torch.no_grad():
+        hip = Rm.render_rays(o, d, est, mc, white_bkgd=True, device=dev, model_fine=mf, u=u.to(dev), u_fine=uf.to(dev))
+    kw = dict(near=2.0, far=6.0, n_samples=S, n_importance=NI, u=u, u_fine=uf, white_bkgd=True, emulate=prec)
+    emu64 = oracle(o, d, sd_c, sd_f, cfg_of(L), torch.float64, **kw)
+    emu32 = oracle(o, d, sd_c, sd_f, cfg_of(L), torch.float32, **kw)
+    H, P, T = outputs(hip), outputs(emu32), outputs(emu64)
+    worst = {}
+    for k in ("rgb_map", "depth_map", "weights", "opacity"):
+        eh, ep = np.abs(H[k] - T[k]), np.abs(P[k] - T[k])
+        fl = FLOOR[k] * 10
+        worst[k] = (float(eh.max()), float(ep.max()), float(np.percentile(eh, 99)), float(np.percentile(ep, 99)))
+        assert eh.max() <= 2.0 * ep.max() + fl and np.percentile(eh, 99) <= 2.0 * np.percentile(ep, 99) + fl, \
+            f"{prec} {k}: max / p99 error vs the float64 emulation {eh.max():.2e} / {np.percentile(eh, 99):.2e}, the " \
+            f"float32 emulation's {ep.max():.2e} / {np.percentile(ep, 99):.2e}"
+    print("config5", prec, {k: tuple(f"{x:.1e}" for x in v) for k, v in worst.items()})
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
 def test_single_pass_two_groups_per_wave_ragged_shapes(dev, prec):
     """The single-pass modes of 256-wide networks run 32 samples per wave in 256-sample tiles (two 16-sample groups
     sharing every weight operand): sizes that end inside a group, a wave or a tile, ray counts below the rays of one
