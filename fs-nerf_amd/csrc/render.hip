@@ -268,20 +268,25 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
       coarse_stage(r0);
       for (int e = tid; e < GRP_G * (GRP_SO + 1); e += kThreads) {
         const int g = e / (GRP_SO + 1), i = e - g * (GRP_SO + 1);
-        if (r0 + g < GRP_R) a.edges_out[(r0 + g) * (GRP_SO + 1) + i] = S_.edgesF[e];
+        // (streaming: written once here, read once below, 494 MB per 800x800 frame - kept out of the way of the
+        // weight streams the XCD's L2 is there for)
+        if (r0 + g < GRP_R) __builtin_nontemporal_store(S_.edgesF[e], a.edges_out + (r0 + g) * (GRP_SO + 1) + i);
       }
       lds_barrier();
     }
-    // the edges are read back by this workgroup only (same CU: the stores went through to L2, the lines were never
-    // in this CU's L1): every store issued, then a workgroup barrier
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // The edges are read back by this workgroup only.  Release / acquire at workgroup scope around the barrier: every
+    // store of this workgroup is performed before any wave of it reads the buffer back, and no read-back is served
+    // from a line fetched before the barrier - stated to the compiler and the hardware instead of relying on the
+    // dispatch-start L1 invalidate and on phase 1 never touching the buffer.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
       const int64_t r0 = grp * GRP_G;
       load_rays(r0);
       for (int e = tid; e < GRP_G * (GRP_SO + 1); e += kThreads) {
         const int g = e / (GRP_SO + 1), i = e - g * (GRP_SO + 1);
-        S_.edgesF[e] = a.edges_out[min(r0 + g, GRP_R - 1) * (GRP_SO + 1) + i];
+        S_.edgesF[e] = __builtin_nontemporal_load(a.edges_out + min(r0 + g, GRP_R - 1) * (GRP_SO + 1) + i);
       }
       lds_barrier();
       fine_stage(r0, S_.edgesF, false);

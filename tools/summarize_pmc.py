@@ -15,18 +15,19 @@ kern = sys.argv[2] if len(sys.argv) > 2 else "k_render_fused"
 prec = sys.argv[3] if len(sys.argv) > 3 else "fp16x3"
 sys.path.insert(0, ROOT)
 src = os.path.join(ROOT, "gpurun_out", f"pmc_{tag}")
-tot, ndisp, dur = {}, {}, []
+tot, disp, dur = {}, {}, []
 for p in sorted(glob.glob(os.path.join(src, "p*", "*", "*counter_collection.csv"))):
-    seen = set()
     for r in csv.DictReader(open(p)):
         if kern not in r["Kernel_Name"]:
             continue
-        tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-        seen.add(r["Dispatch_Id"])
+        c = r["Counter_Name"]
+        tot[c] = tot.get(c, 0.0) + float(r["Counter_Value"])
+        disp.setdefault(c, set()).add((p, r["Dispatch_Id"]))
         dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9)
-    for c in {r for r in tot}:
-        ndisp.setdefault(c, max(len(seen), 1))
-n = 1  # bench.py --steps 1 --warmup 0: one launch per pass
+# launches of the kernel per pass (bench.py --steps 1 --warmup 0: one for the render workload, two for occgrid, whose
+# rank 0 renders the frame once more for the sample counts): counters are averaged per launch
+n = max([len(v) for v in disp.values()] + [1])
+tot = {c: v * n / len(disp[c]) for c, v in tot.items()}
 import bench  # noqa: E402  (csrc_sha only; no GPU use)
 out = {"kernel": kern, "precision": prec, "csrc_sha": bench.csrc_sha(), "launches_per_pass": n, "counters_per_launch": {k: v / n for k, v in sorted(tot.items())}}
 c = out["counters_per_launch"]
