@@ -11,10 +11,11 @@ fused kernel `fsn_mlp_fwd`.  In training mode with autograd enabled, `forward(x,
 instead (`_NerfTrainFn`: `fsn_nerf_train_fwd` / `_bwd`, hand-written MFMA forward-with-savers, dgrad chain and
 split-K wgrad kernels in the same precision mode).  Additions over the reference: an optional frequency mask
 (`set_freq_mask`) and the arithmetic mode `precision`:
-  "fp16x3" (default) three fp16 MFMA passes on high/low parts, fp32 accumulate: fp32-class accuracy (the 1e-4
-            parity mode).  Representable range of fp16: |activation|, |weight| < 65504.  The kernels raise a device
-            flag when a hidden activation leaves that range; `forward` / `render_rays` then re-run the call in
-            "bf16x3" and keep that mode (a RuntimeWarning is issued) - inf/NaN are never returned silently;
+  "fp16x3" (default) three fp16 MFMA passes on high / scaled-low parts with a separate correction accumulator, fp32
+            accumulate: fp32-class accuracy (the 1e-4 parity mode) for hidden-layer scales from 2^-14 to 65504.  The
+            kernels raise a device flag at either end (a value reached fp16 infinity; a layer whose largest activation
+            over a wavefront is an fp16 subnormal); `forward` / `render_rays` then re-run the call in "bf16x3" and
+            keep that mode (a RuntimeWarning is issued) - never silent, inf/NaN are never returned;
   "bf16x3"  the same split on bf16 parts: no range limit, ~1e-5 per product;
   "fp16x2"  two passes (weights high part only): measured accuracy in DESIGN.md, not a parity mode;
   "bf16" / "fp16"  one pass (BASELINE config 5), tolerance stated in the tests.

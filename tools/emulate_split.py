@@ -13,7 +13,8 @@ products exact, sums in float32.  Schemes:
   fp16        single pass
 Networks: default nn.Linear init (seed 42) with the sigma head x64 (+3) as the parity tests use, hidden activations
 rescaled by s (tests/test_parity_fp64.py:scaled_sd).  Errors against a float64 evaluation, 20,000 points in the
-+-1.5 box: sigma relative to max |sigma|... no: RELATIVE TO EACH sigma's own magnitude floor 1e-2 max, rgb absolute.
++-1.5 box, maximum over the points: sigma relative to its own magnitude (floored at 1 % of the largest |sigma|), rgb
+absolute.  Scheme names here: "fp16x3" = rounds 1-2 (unscaled low parts), "fp16x3s" = round 3 (what the kernels do).
 
 usage: python tools/emulate_split.py [--points N] [--json out.json]
 """
