@@ -171,14 +171,9 @@ class NeRF(nn.Module):
         the ranks first (every rank makes the same number of training calls, so all of them are here together): a
         rank that overflowed and one that did not must not continue in different arithmetic."""
         w = self._train_status(dev)
-        bits = int(w.item())
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and \
-                torch.distributed.get_world_size() > 1:
-            t = torch.tensor([bits], dtype=torch.int32, device=dev if torch.distributed.get_backend() != "gloo" else "cpu")
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            # (MAX of bit masks 0..3: 3 if any rank has both or the largest single; refine to an OR with two rounds
-            # only if more bits are ever added - both bits lead to the same fallback)
-            bits = int(t.item())
+        from ..shard import max_bits_over_ranks
+        # (MAX of bit masks 0..3: both bits lead to the same fall-back, so the largest mask is enough)
+        bits = max_bits_over_ranks(int(w.item()), dev)
         if bits:
             w.zero_()
         return bits & (L.FSN_STATUS_FP16_RANGE | L.FSN_STATUS_FP16_SMALL)

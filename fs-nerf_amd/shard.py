@@ -6,7 +6,7 @@ frame (`shard_rows`, then `fsn_get_rays(row0, nrows)` + the fused launch).  The 
 are outside the timed path: `gather_rows` to assemble one image, `max_over_ranks` for timing.
 The backend is whatever the process group was created with ("nccl" = RCCL on the GPU box,
 "gloo" in the CPU tests)."""
-from typing import Tuple
+from typing import Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -31,6 +31,17 @@ def max_over_ranks(value: float, device) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def max_bits_over_ranks(bits: int, device=None) -> int:
+    """MAX over the ranks of a small non-negative integer (the fp16 range words of a training step: every rank must
+    take the same fall-back decision).  One tiny collective; identity without a process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return int(bits)
+    on_host = dist.get_backend() == "gloo" or device is None
+    t = torch.tensor([int(bits)], dtype=torch.int32, device="cpu" if on_host else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
 
 
 def gather_rows(local: torch.Tensor, H: int) -> torch.Tensor:
@@ -93,11 +104,15 @@ class FlatGrads:
         self.flat.zero_()
         self.bind()
 
-    def allreduce(self, average: bool = True) -> None:
+    def allreduce(self, average: bool = True, flag: Optional[float] = None) -> None:
+        """`flag`: this rank's "skip this step" value for the bucket's extra slot; default = the device's step flag
+        (ops.step_flag, raised by an fp16-mode training launch that overflowed) on the GPU, 0 on the CPU."""
         self.bind()
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
-        if self._buf.is_cuda:  # this rank's step flag (device word of the training launches) into the bucket's slot
+        if flag is not None:
+            self.flag_slot.fill_(float(flag))
+        elif self._buf.is_cuda:  # this rank's step flag (device word of the training launches) into the bucket's slot
             from . import ops
             self.flag_slot.copy_((ops.step_flag(self._buf.device) & 1).to(torch.float32))
         flat = self._buf

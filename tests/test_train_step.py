@@ -419,6 +419,50 @@ def _dp_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _flag_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+        b = shard.FlatGrads(list(net.parameters()))
+        out = []
+        for step, flags in enumerate(((0.0, 0.0), (0.0, 1.0), (1.0, 1.0))):
+            for i, p in enumerate(net.parameters()):
+                p.grad.fill_(float(rank + 1) * (i + 1))
+            b.allreduce(average=False, flag=flags[rank])
+            out.append((float(b.flag_slot.item()), float(net[0].weight.grad.flatten()[0]), b.flat.numel()))
+            b.flag_slot.zero_()
+        bits = [shard.max_bits_over_ranks(pair[rank]) for pair in ((0, 0), (0, 2), (1, 0), (3, 1))]
+        q.put((rank, out, bits))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overflow_flag_travels_in_the_gradient_bucket_gloo():
+    """in data-parallel training one rank may overflow fp16 while the others do not.  The bucket of
+    the step's ONE all-reduce carries a flag slot behind the gradients (sum: > 0 on every rank when any rank raised
+    it; `fsn_adam_step(skip_count)` then skips the update everywhere), and the host's amortised look at the range
+    word takes the MAX over the ranks, so that all ranks fall back to bf16x3 together."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_flag_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out, bits in res:
+        assert [o[0] for o in out] == [0.0, 1.0, 2.0], "flag slot = number of ranks that raised it, on every rank"
+        assert all(o[1] == 3.0 for o in out), "gradients are summed as before"
+        assert all(o[2] == 5 * 7 + 7 + 7 * 3 + 3 for o in out), "the gradient view keeps its size"
+        assert bits == [0, 2, 1, 3], "MAX over ranks of the range words"
+
+
 def test_gradient_allreduce_two_ranks_gloo():
     world = 2
     ctx = mp.get_context("spawn")
