@@ -139,6 +139,20 @@ def body_w8_corr(fillers, barrier, dma, order):
                     for _ in range(4 * fn // fd if fd else 0):
                         ins.append(FILL[state["fi"] % 4]); state["fi"] += 1
         return ins, 24
+    if order == "p32":
+        # 32-KiB phases: one barrier and eight LDS-DMA loads per 16 units (the loop body covers two 8-unit rounds)
+        for u in range(16):
+            if u == 14:
+                ins.append("s_waitcnt vmcnt(0)")
+                ins.append("s_barrier")
+                pending.extend(f"global_load_lds_dwordx4 %[voff], %[gb] offset:{1024*i}" for i in range(8))
+            read(u)
+            if u % 2 == 0:
+                ins.append("s_waitcnt lgkmcnt(2)")
+            t, k = u % 2, (u // 2) % 4
+            (ah, al), (bh, bl) = A(u), B(k)
+            mf(E(t), ah, bh); mf(C(t), al, bh); mf(C(t), ah, bl)
+        return ins, state["nm"]          # (48 MFMAs per loop body: "cyc/phase" is per 16 units here)
     if order == "e1c2":
         for u in range(8):
             opening(u)
@@ -172,8 +186,8 @@ def body_w8_corr(fillers, barrier, dma, order):
 
 
 VARIANTS = []
-for order in ("e3", "e1c2", "f8", "e1c2", "f8"):
-    for fillers in ((1, 2), (3, 4), (1, 1)):
+for order in ("e1c2", "p32", "e1c2", "p32", "e1c2", "p32"):
+    for fillers in ((3, 4),):
         VARIANTS.append(("w8", fillers, 1, "spread", order))
 for shape in ():
     for fillers in ((0, 1), (1, 2), (1, 1), (2, 1), (3, 1)):
