@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
     const int64_t ngr = (k.a.R + k.G - 1) / k.G;
     const int64_t mine = ngr > (int64_t)blockIdx.x ? (ngr - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     const uint32_t repC = k.two_phase ? (uint32_t)(mine * k.nsubC) : (uint32_t)k.nsubC;
-    const uint32_t repF = k.two_phase ? (uint32_t)(mine * k.nsubF) : (uint32_t)k.nsubF;
+    const uint32_t repF = k.two_phase == 2 ? 0u : (k.two_phase ? (uint32_t)(mine * k.nsubF) : (uint32_t)k.nsubF);
     st.init(smem, k.netC.blob + k.netC.stream_off, GRP_HIER ? (uint32_t)k.netC.nph_density : 0u, repC,
             k.netF.blob + k.netF.stream_off, (uint32_t)k.netF.nph_full, repF);
   }
@@ -281,6 +281,10 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (S_.two_phase == 2) {  // sampler only (fsn_render_args.two_phase == 2): the resampled edges are the result
+      st.drain();
+      return;
+    }
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
       const int64_t r0 = grp * GRP_G;
       load_rays(r0);
@@ -366,7 +370,14 @@ extern "C" int fsn_render_rays_fused(const fsn_mlp_desc* desc, int prec, const v
   const int rc = build_geom(*desc, prec, G, &why);
   FSN_REQUIRE(rc == FSN_OK, rc, "fsn_render_rays_fused: %s", why);
   if (a.R == 0) return FSN_OK;
-  FSN_REQUIRE(blob_fine && a.colors && a.opacity && a.depth, FSN_E_INVALID, "fsn_render_rays_fused: null pointer");
+  const bool sampler_only = a.two_phase == 2;
+  if (sampler_only) {
+    FSN_REQUIRE(a.n_imp > 0 && blob_coarse && a.edges_out, FSN_E_INVALID,
+                "fsn_render_rays_fused: two_phase == 2 (sampler only) needs n_imp > 0, blob_coarse and edges_out");
+    if (!blob_fine) blob_fine = blob_coarse;
+  } else {
+    FSN_REQUIRE(blob_fine && a.colors && a.opacity && a.depth, FSN_E_INVALID, "fsn_render_rays_fused: null pointer");
+  }
   if (a.rays_o) {
     FSN_REQUIRE(a.rays_d, FSN_E_INVALID, "fsn_render_rays_fused: rays_o without rays_d");
   } else {
@@ -392,7 +403,7 @@ extern "C" int fsn_render_rays_fused(const fsn_mlp_desc* desc, int prec, const v
   k.a = a;
   k.G = k.nsubC = k.nsubF = 0;  // (set per instantiation in launch_render: the tile is 128 or 256 samples)
   k.step = (float)(((double)a.far - (double)a.near) / a.S);
-  k.two_phase = (a.two_phase && a.n_imp > 0 && a.edges_out) ? 1 : 0;
+  k.two_phase = sampler_only ? 2 : ((a.two_phase && a.n_imp > 0 && a.edges_out) ? 1 : 0);
   k.cam_hw = (float)(a.cam_W * 0.5);
   k.cam_hh = (float)(a.cam_H * 0.5);
   k.cam_f = (float)a.cam_focal;

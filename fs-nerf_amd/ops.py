@@ -448,6 +448,47 @@ def render_fused(pm_coarse: Optional[PackedMLP], pm_fine: PackedMLP, rays_o: Opt
     return colors, opacity, depth, ex
 
 
+def sample_fused(pm_coarse: PackedMLP, rays_o: Tensor, rays_d: Tensor, *, near: float, far: float, n_samples: int,
+                 n_importance: int, u: Optional[Tensor] = None, u_fine: Optional[Tensor] = None,
+                 pos_mask: Optional[Tensor] = None, dir_mask: Optional[Tensor] = None,
+                 want_weights: bool = False):
+    """The hierarchical sampler as ONE launch (fsn_render_rays_fused with two_phase = 2): stratified edges -> density
+    pass of `pm_coarse` -> weights -> inverse-CDF resampling -> sorted union.  -> edges [R, S+NI+1] (and the coarse
+    weights [R,S] when asked for): what StratifiedEstimator.sampling builds from five launches around a sigma_fn."""
+    S, NI = n_samples, n_importance
+    if NI <= 0:
+        raise ValueError("sample_fused: hierarchical sampling only (n_importance > 0)")
+    o, d = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d")
+    R, dev = o.shape[0], o.device
+    mode, u = _u_mode(u, R, S)
+    a = L.RenderArgs()
+    a.R, a.rays_o, a.rays_d = R, o.data_ptr(), d.data_ptr()
+    a.near, a.far, a.S, a.n_imp, a.u_mode = float(near), float(far), S, NI, mode
+    keep = [o, d, u]
+    a.u = None if u is None else u.data_ptr()
+    if u_fine is not None:
+        u_fine = _f32(u_fine, "u_fine")
+        assert tuple(u_fine.shape) == (R, NI)
+        a.u_fine = u_fine.data_ptr()
+    for name, m in (("pos_mask", pos_mask), ("dir_mask", dir_mask)):
+        if m is not None:
+            m = _f32(m, name)
+            keep.append(m)
+            setattr(a, name, m.data_ptr())
+    edges = torch.empty(R, S + NI + 1, device=dev)
+    a.edges_out = edges.data_ptr()
+    wc = torch.empty(R, S, device=dev) if want_weights else None
+    if wc is not None:
+        a.weights_coarse = wc.data_ptr()
+    a.two_phase = 2
+    a.status = status_word(dev).data_ptr()
+    if R > 0:
+        with torch.cuda.device(dev):
+            L.check(L.lib().fsn_render_rays_fused(C.byref(pm_coarse.desc), pm_coarse.prec, _p(pm_coarse.blob), None,
+                                                  C.byref(a), _stream()), "fsn_render_rays_fused")
+    return (edges, wc) if want_weights else edges
+
+
 # ------------------------------------------------------------------ "next" rows (SURVEY 8f)
 class _OcclusionRegFn(torch.autograd.Function):
     @staticmethod

@@ -253,9 +253,28 @@ def render_rays(rays_o: Tensor, rays_d: Tensor, estimator, model: nn.Module, tra
             x = to + td * (t_starts + t_ends)[:, None] / 2.0
             return model(x).squeeze(-1)
 
-        ray_indices, t_starts, t_ends = estimator.sampling(
-            rays_o, rays_d, sigma_fn=sigma_fn, render_step_size=render_step_size, stratified=train,
-            near_plane=0.0, far_plane=1e10, **({"u": u, "u_fine": u_fine} if isinstance(estimator, StratifiedEstimator) else {}))
+        if isinstance(estimator, StratifiedEstimator) and estimator.n_importance > 0 and isinstance(model, NeRF) and \
+                model.precision in ("fp16x3", "bf16x3", "fp16", "bf16", "fp16x2"):
+            # the hierarchical sampler in front of the training forward as ONE launch (ops.sample_fused) instead of
+            # stratified edges -> packed -> density pass -> weights -> resampling -> packed: same edges bit for bit
+            R_, dev_ = rays_o.shape[0], rays_o.device
+            uu = u if (u is not None or not train) else estimator.draw_u(R_, dev_)
+            uf = u_fine if (u_fine is not None or not train) else \
+                torch.rand(R_, estimator.n_importance, device=dev_, generator=estimator.generator)
+            near_, far_ = estimator.bounds(0.0, 1e10)
+            kw_s = dict(near=near_, far=far_, n_samples=estimator.n_samples, n_importance=estimator.n_importance, u=uu,
+                        u_fine=uf, pos_mask=model._mask(model.pos_mask, dev_), dir_mask=model._mask(model.dir_mask, dev_))
+            with torch.no_grad():
+                edges = ops.sample_fused(model.packed(), rays_o, rays_d, **kw_s)
+                bits = ops.range_flags(dev_) if model.range_check is True and model.fp16_family(model.PRECISIONS[model.precision]) else 0
+                if bits:
+                    model.fall_back("the sampler's density pass", bits)
+                    edges = ops.sample_fused(model.packed(), rays_o, rays_d, **kw_s)
+                ray_indices, t_starts, t_ends = ops.edges_to_packed(edges)
+        else:
+            ray_indices, t_starts, t_ends = estimator.sampling(
+                rays_o, rays_d, sigma_fn=sigma_fn, render_step_size=render_step_size, stratified=train,
+                near_plane=0.0, far_plane=1e10, **({"u": u, "u_fine": u_fine} if isinstance(estimator, StratifiedEstimator) else {}))
         fine = model_fine if model_fine is not None else model
 
         def rgb_sigma_fn(t_starts, t_ends, ray_indices):

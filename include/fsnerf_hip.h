@@ -193,7 +193,11 @@ typedef struct fsn_render_args {
   /* Hierarchical launches over many rays run in two phases when `edges_out` is given (it doubles as the hand-over
    * buffer): every workgroup first runs the coarse pass + resampling of ALL its ray groups, then the fine pass of
    * all of them, so that an XCD's L2 holds ONE network's weight stream at a time (2.0 / 2.3 MB of the 4 MiB)
-   * instead of both.  Results are identical.  two_phase: 0 = never, 1 = whenever edges_out != NULL and n_imp > 0. */
+   * instead of both.  Results are identical.  two_phase: 0 = never, 1 = whenever edges_out != NULL and n_imp > 0,
+   * 2 = SAMPLER ONLY: the launch stops after the coarse pass + resampling; edges_out [R,S+n_imp+1] (and
+   * weights_coarse when given) are its results, the per-ray outputs are not written and may be NULL, blob_fine may be
+   * NULL.  This is estimator.sampling of the hierarchical sampler (stratified edges -> density pass -> weights ->
+   * inverse-CDF resampling -> sorted union) as ONE launch in front of the training forward. */
   int32_t two_phase;
 } fsn_render_args;
 

@@ -295,6 +295,50 @@ def test_ray_form_forward_is_the_reference_closures_bit_for_bit():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("net,rays,S,NI,jitter", [((8, 256), "ndc", 64, 128, True), ((8, 256), "orbit", 64, 128, False),
+                                                  ((4, 128), "orbit", 96, 32, True), ((8, 256), "orbit", 128, 256, True)])
+def test_fused_sampler_is_the_five_launch_sampler(net, rays, S, NI, jitter):
+    """VERDICT r2 item 6 ("fuse sampler + density pass"): in front of the training forward the hierarchical sampler is
+    ONE launch (the fused render kernel stopped after its coarse stage, fsn_render_args.two_phase = 2) instead of
+    stratified edges -> packed intervals -> density pass -> weights -> resampling -> packed intervals.  Same edges and
+    coarse weights bit for bit (same arithmetic: stratified_edge, the MLP tile, weights / sample_pdf_merge per ray)."""
+    from fs_nerf_amd import ops
+    from fs_nerf_amd.core.models import NeRF
+    from fs_nerf_amd.render import rendering as Rm
+    from test_parity_fp64 import make_sd, ndc_rays, orbit_rays
+    dev = torch.device("cuda:0")
+    Lx, Dx = net
+    m = NeRF(3, 3, Lx, Dx, (4,), pos_fn={"n_freqs": 10, "log_space": True}, dir_fn={"n_freqs": 4, "log_space": True})
+    m.load_state_dict(make_sd(Lx, Dx, 42))
+    m = m.to(dev).eval()
+    R = 1003
+    if rays == "ndc":
+        o, d, gen = ndc_rays(R, 7)
+        near, far = 0.0, 1.0
+    else:
+        o, d, gen = orbit_rays(R, 7, 400, 555.5)
+        near, far = 2.0, 6.0
+    o, d = o.to(dev), d.to(dev)
+    u = torch.rand(R, generator=gen).to(dev) if jitter else None
+    uf = torch.rand(R, NI, generator=gen).to(dev) if jitter else None
+    est = Rm.StratifiedEstimator(near, far, S, NI)
+    with torch.no_grad():
+        ri, t0, t1 = est.sampling(o, d, sigma_fn=lambda a, b, c: m(o[c] + d[c] * (a + b)[:, None] / 2.0).squeeze(-1), u=u, u_fine=uf)
+        edges, wc = ops.sample_fused(m.packed(), o, d, near=near, far=far, n_samples=S, n_importance=NI, u=u, u_fine=uf,
+                                     want_weights=True)
+    want = torch.cat([t0.reshape(R, S + NI), t1.reshape(R, S + NI)[:, -1:]], dim=1)
+    assert torch.equal(edges, want), f"max |d edge| {float((edges - want).abs().max()):.3e}"
+    # and through render_rays(train=True): the packed intervals the training forward sees
+    m.train()
+    est.train()
+    (rgb, _, _, ex), ri2, tv = Rm.render_rays(o, d, est, m, train=True, white_bkgd=True, device=dev, u=u if jitter else torch.zeros(R, device=dev),
+                                             u_fine=uf if jitter else torch.linspace(0, 1, NI, device=dev)[None].expand(R, NI).contiguous())
+    assert rgb.requires_grad and ri2.numel() == R * (S + NI)
+    if jitter:
+        assert torch.equal(tv, (t0 + t1) / 2.0)
+
+
+@pytest.mark.gpu
 def test_c4_shape_whole_step_gradients_end_to_end():
     """BASELINE configs[3]'s training shape: ONE 8x256 network, 256 forward-facing NDC rays, 64 + 128 samples,
     render_rays(train=True) -> mse -> backward, every parameter gradient against float64 autograd on the oracle -
