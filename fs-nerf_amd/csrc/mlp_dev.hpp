@@ -100,6 +100,7 @@ struct WStream {
   char* ring;
   uint32_t ring_lds;  // LDS byte address of the ring (M0 base of the LDS-DMA)
   uint32_t m0_base;   // ... + this wave's share of a phase (loader waves; SGPR)
+  uint32_t is_loader;  // this wave issues LDS-DMA (one per SIMD)
   const char *ptrA, *ptrB;
   uint32_t nphA, nphB, repA, repB;
   // stager state
@@ -136,16 +137,13 @@ struct WStream {
   // form + immediate offsets need one M0 write and no per-load address VALU.  The immediate
   // offset of global_load_lds advances BOTH the global and the LDS address.
   __device__ __forceinline__ void stage() {
-    const uint32_t wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) ^ FSN_LOADER_XOR);
-    // (readfirstlane: the value is wave-uniform, but the "s" constraint needs the compiler to know it)
-    const uint32_t m0v = __builtin_amdgcn_readfirstlane(ring_lds + s_slot * kPhaseBytes + wave * (kGldsPerWave * 1024));
+    // wave-uniform SALU arithmetic only (as next_stage below): the M0 base and the loader predicate are formed once
+    // in init(), the end of a pass is a real branch
+    const uint32_t m0v = m0_base + s_slot * kPhaseBytes;
     const uint32_t voff = ((threadIdx.x >> 6) ^ FSN_LOADER_XOR) * (kGldsPerWave * 1024) + (threadIdx.x & 63) * 16;
-    const uint64_t sp = (uint64_t)s_ptr;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sp);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(sp >> 32));
-    const uint64_t sbase = ((uint64_t)hi << 32) | lo;
+    const uint64_t sbase = (uint64_t)s_ptr;
     uint32_t keep;
-    if (wave < (uint32_t)kLoaders) {
+    if (is_loader) {
       asm volatile(
           "s_mov_b32 %0, m0\n\t"
           "s_mov_b32 m0, %2\n\t"
@@ -162,13 +160,17 @@ struct WStream {
     static_assert(kGldsPerWave == 4, "stage() issues exactly 4 loads per loader wave");
     s_ptr += kPhaseBytes;
     s_slot = slot_add(s_slot, 1);
-    if (--s_left == 0) advance_pass_();
+    if (__builtin_expect(--s_left == 0, 0)) {
+      asm volatile("" ::: "memory");  // keep it a branch (no if-conversion into s_cselect chains)
+      advance_pass_();
+    }
   }
   __device__ __forceinline__ void init(char* ring_, const char* pA, uint32_t nA, uint32_t rA, const char* pB,
                                        uint32_t nB, uint32_t rB) {
     ring = ring_;
     ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring_;
     m0_base = __builtin_amdgcn_readfirstlane(ring_lds + ((threadIdx.x >> 6) ^ FSN_LOADER_XOR) * (kGldsPerWave * 1024));
+    is_loader = __builtin_amdgcn_readfirstlane((((threadIdx.x >> 6) ^ FSN_LOADER_XOR) < (uint32_t)kLoaders) ? 1u : 0u);
     ptrA = pA; nphA = nA; repA = nA ? rA : 0;
     ptrB = pB; nphB = nB; repB = nB ? rB : 0;
     s_rep = 0; s_slot = 0; c_slot = 0;
