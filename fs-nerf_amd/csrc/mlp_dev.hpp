@@ -88,6 +88,10 @@ constexpr int kGldsPerWave = kPhaseBytes / 1024 / kLoaders;  // 1-KiB LDS-DMA in
 constexpr int kRingBytes = kNSlot * kPhaseBytes;
 constexpr int kAuxCapFloats = 3456;  // LDS reserved per network for biases / heads (8x256 needs 3392)
 constexpr int kTileCols = 128;       // samples per workgroup tile = columns of a T-layout tile (train_fused.hip)
+constexpr int kTRow = 16;            // T-layout: dwords between consecutive pair-rows of one 16-sample chunk
+// T-layout (train_fused.hip) of a saved matrix with 2 P rows, per 128-sample tile and plane: [chunk of 16 samples][P
+// pair-rows][16 samples] dwords.  Offset of (pair-row pr, sample s of the tile) inside the plane:
+__host__ __device__ constexpr int64_t t_layout_off(int P, int pr, int s) { return (int64_t)(s >> 4) * P * kTRow + pr * kTRow + (s & 15); }
 
 struct Frag {  // one k-step (32 features x 16 samples) of activations as MFMA B operand
   s16x8 hi, lo;
@@ -480,15 +484,15 @@ __device__ __forceinline__ void encode(float x0, float x1, float x2, int n_freqs
   for (int k = 0; k < NKS; ++k) split_store<F16, X3>(&v[8 * k], out[k]);
   if constexpr (SAVE) {
     // packed T-layout (train_fused.hip): slots (k, 2i), (k, 2i+1) are rows 32k + 8g + 2i, +1 = pair-row 16k + 4g + i;
-    // `save` = this lane's column at pair-row 4g of the high-part plane, the low-part plane 16 NKS pair-rows further
+    // `save` = this lane's sample at pair-row 4g of the high-part plane, the low-part plane 16 NKS x 128 dwords further
     typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 #pragma unroll
     for (int k = 0; k < NKS; ++k) {
       const u32x4 h = __builtin_bit_cast(u32x4, out[k].hi), l = __builtin_bit_cast(u32x4, out[k].lo);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        __builtin_nontemporal_store(h[i], save + (16 * k + i) * kTileCols);
-        if (X3) __builtin_nontemporal_store(l[i], save + (16 * NKS + 16 * k + i) * kTileCols);
+        __builtin_nontemporal_store(h[i], save + (16 * k + i) * kTRow);
+        if (X3) __builtin_nontemporal_store(l[i], save + 16 * NKS * kTileCols + (16 * k + i) * kTRow);
       }
     }
   }
@@ -634,6 +638,12 @@ __device__ __forceinline__ void pair_epilogue(const NetDev& net, int tp, const f
       constexpr float IK = F16 ? 1.0f / kLoScaleF16 : 1.0f;
       typedef __attribute__((ext_vector_type(2))) float f32x2;
       const f32x2 ik2 = {IK, IK};
+#ifdef FSN_EPI_SCALAR_FMA  // timing experiment: eight v_fma_f32 in place of four v_pk_fma_f32
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] = __builtin_fmaf(cor0[j], IK, acc0[j]); v[4 + j] = __builtin_fmaf(cor1[j], IK, acc1[j]); }
+      (void)ik2;
+      if constexpr (false)
+#endif
 #pragma unroll
       for (int j = 0; j < 4; j += 2) {  // v_pk_fma_f32: two values per instruction
         const f32x2 a0 = {acc0[j], acc0[j + 1]}, c0 = {cor0[j], cor0[j + 1]};

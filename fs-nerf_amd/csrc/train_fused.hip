@@ -13,13 +13,16 @@
 //   k_heads_wgrad : sigma / rgb head weights (1 and 3 output rows): HBM-bound row dot products.
 //
 // "Packed T-layout" of every saved matrix with R rows (features): tiles of 128 samples (one workgroup tile),
-// [tile][plane][R/2 pair-rows][128 samples] x 32 bit.  Plane 0 holds the 16-bit HIGH parts, plane 1 the LOW parts (x3
-// modes only) of the value in the mode's 16-bit format; dword (q, s) = part(row 2q, s) | part(row 2q+1, s) << 16.
-// These are the words the forward / backward epilogues form anyway for the next GEMM's B operand (a packed pair of
-// neighbouring features of one sample), so saving costs the stores only - and the weight-gradient GEMM, whose
-// contraction runs along the samples, loads 32 contiguous bytes per lane and has both rows' MFMA operands after four
-// v_perm_b32 each, instead of splitting fp32 values itself (it was bound by exactly that VALU work: 3.44 ms at
-// 3.8 TB/s before).  Same bytes as fp32 in the x3 modes, half in the single-pass modes.
+// [tile][plane][chunk of 16 samples][R/2 pair-rows][16 samples] x 32 bit (mlp_dev.hpp, t_layout_off).  Plane 0 holds
+// the 16-bit HIGH parts, plane 1 the LOW parts (x3 modes only) of the value in the mode's 16-bit format; dword (q, s) =
+// part(row 2q, s) | part(row 2q+1, s) << 16.  These are the words the forward / backward epilogues form anyway for the
+// next GEMM's B operand (a packed pair of neighbouring features of one sample), so saving costs the stores only - and
+// the weight-gradient GEMM, whose contraction runs along the samples, has both rows' MFMA operands after four
+// v_perm_b32 each, instead of splitting fp32 values itself.  Same bytes as fp32 in the x3 modes, half in the
+// single-pass modes.  Chunk-major inside a tile (round 3; rounds 1-2: [pair-row][128 samples]): a wave of the forward /
+// backward kernels owns 16 samples, so its epilogue stores of neighbouring pair-rows are now neighbours in memory
+// (64-byte runs 64 bytes apart instead of 512), and what the wgrad kernels consume per k-step - all rows of 16 samples
+// - is ONE contiguous run per plane (8 KiB for 256 rows) instead of 64 bytes out of every 512.
 //
 // Precision: as the forward, split 16-bit x 3 passes with fp32 accumulation.  In the fp16 modes d(out) is
 // multiplied by a power-of-two `grad_scale` on entry (and the result divided by it in the reduce) so that the
@@ -121,14 +124,14 @@ static int make_fused_layout(const fsn_mlp_desc& d, int prec, int64_t n, FusedLa
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 // Store the 16-bit parts of output pair tp (accumulator order: dword i of a part = rows 32 tp + 16 (i>>1) + 4 g +
-// 2 (i&1), +1 = pair-row 16 tp + 8 (i>>1) + 2 g + (i&1)).  p: this lane's column at pair-row 2g of the high-part
-// plane of its tile; plane: dwords between the two planes (R/2 x 128).
+// 2 (i&1), +1 = pair-row 16 tp + 8 (i>>1) + 2 g + (i&1)).  p: this lane's sample at pair-row 2g of the high-part
+// plane of its tile (t_layout_off); plane: dwords between the two planes (R/2 x 128).
 template <bool X3>
 __device__ __forceinline__ void store_pair_parts(uint32_t* p, int64_t plane, int tp, const Frag& o) {
   const u32x4 h = __builtin_bit_cast(u32x4, o.hi), l = __builtin_bit_cast(u32x4, o.lo);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    uint32_t* q = p + (16 * tp + 8 * (i >> 1) + (i & 1)) * kTC;
+    uint32_t* q = p + (16 * tp + 8 * (i >> 1) + (i & 1)) * kTRow;
     FSN_STREAM_STORE(h[i], q);
     if (X3) FSN_STREAM_STORE(l[i], q + plane);
   }
@@ -231,13 +234,13 @@ __global__ __launch_bounds__(kThreads) void k_train_fwd(TrainFwdArgs a) {
     const TileSrcT src{in_lds + col * 6};
     FwdSaver sv;
     uint32_t* wsu = reinterpret_cast<uint32_t*>(a.ws);
-    sv.h0 = wsu + a.off_h + (tile * D + 2 * g) * kTC + col;
+    sv.h0 = wsu + a.off_h + tile * D * kTC + t_layout_off(D / 2, 2 * g, col);
     sv.hstride = a.h_stride;
     sv.hplane = (D / 2) * kTC;
-    sv.bo = wsu + a.off_bo + (tile * (D / 2) + 2 * g) * kTC + col;
+    sv.bo = wsu + a.off_bo + tile * (D / 2) * kTC + t_layout_off(D / 4, 2 * g, col);
     sv.boplane = (D / 4) * kTC;
-    sv.pe = wsu + a.off_pe + (tile * 64 + 4 * g) * kTC + col;
-    sv.de = wsu + a.off_de + (tile * 32 + 4 * g) * kTC + col;
+    sv.pe = wsu + a.off_pe + tile * 64 * kTC + t_layout_off(32, 4 * g, col);
+    sv.de = wsu + a.off_de + tile * 32 * kTC + t_layout_off(16, 4 * g, col);
     sv.mk0 = reinterpret_cast<uint32_t*>(a.ws + a.off_mask) + ((tile * 4 + g) * kTC + col) * 2;
     sv.mstride = a.mask_stride;
     sv.n_layers = net.n_layers;
@@ -382,8 +385,8 @@ __global__ __launch_bounds__(kThreads) void k_train_bwd(TrainBwdArgs a) {
       dh[0] = dz[0]; dh[kTC] = dz[1]; dh[2 * kTC] = dz[2]; dh[3 * kTC] = dsig;
     }
     uint32_t* wsu = reinterpret_cast<uint32_t*>(a.ws);
-    const int64_t lane_off = (tile * D + 2 * g) * kTC + col;         // pair-row 2g, high-part plane, of a D-row tile
-    const int64_t lane_off_h = (tile * (D / 2) + 2 * g) * kTC + col;  // ... of a D/2-row tile
+    const int64_t lane_off = tile * D * kTC + t_layout_off(D / 2, 2 * g, col);          // pair-row 2g, high-part plane, of a D-row tile
+    const int64_t lane_off_h = tile * (D / 2) * kTC + t_layout_off(D / 4, 2 * g, col);  // ... of a D/2-row tile
     constexpr int64_t planeD = (D / 2) * kTC, planeH = (D / 4) * kTC;
     Frag A[NT], B[NT];
     const uint32_t* mk = reinterpret_cast<const uint32_t*>(a.ws + a.off_mask) + ((tile * 4 + g) * kTC + col) * 2;
@@ -467,6 +470,11 @@ struct WgArgs {
 
 template <bool F16>
 __device__ __forceinline__ f32x16 mfma32(const s16x8& a, const s16x8& b, const f32x16& c) {
+#ifdef FSN_WGRAD_NOMFMA  // timing experiment: the memory side of k_wgrad by itself (one VALU op keeps the operands live)
+  f32x16 r = c;
+  r[0] += (float)a[0] * (float)b[0];
+  return r;
+#endif
   if (F16)
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -514,34 +522,84 @@ __device__ __forceinline__ float frag_sum(const s16x8& f, float acc) {
   return acc;
 }
 
-// Workgroup = 8 waves as MG row groups (64 rows of A each: two 32-row MFMA tiles) x CG = 8/MG column groups
-// (BT 32-row tiles of B each).  Per 32-sample chunk: each wave loads its own A pair-rows straight from HBM/L2 (32
-// contiguous bytes per lane, k-step and plane) - MFMA tile 0 takes the EVEN rows of the wave's 64-row block, tile 1
-// the ODD rows, so that both halves of every loaded dword are this lane's operands; the B pair-rows are unzipped
-// into MFMA-operand order in LDS (double buffered, register prefetch of the next chunk).  No fp32 -> 16-bit
-// conversion happens here: the savers stored the parts.  Bias gradient = row sums of A (v_dot2c on the fragments).
-// NW waves per workgroup (8; 4 = two independent workgroups per CU was tried for the 256x256 jobs, see the launch code);
-// blockIdx.z selects the workgroup's block of A_ROWS = 64 MG rows of A.
+// Workgroup = 8 waves as MG row groups (64 rows of A each: two 32-row MFMA tiles) x CG = 8/MG column groups (BT
+// 32-row tiles of B each); blockIdx.z selects the workgroup's block of A_ROWS = 64 MG rows of A.  The contraction runs
+// over the samples in chunks of 16 (one MFMA k-step).
+//
+// This kernel is bound by HBM, not by the matrix pipe (12.9 GB per step at float32-grade storage; timing the memory
+// side and the matrix side of the register-prefetch form of rounds 1-2 separately gave 2.66 ms and 1.97 ms of its
+// 3.08 ms), so the operands travel HBM -> LDS by LDS-DMA (`global_load_lds_dwordx4`), never through
+// registers: a ring of NSTAGE = 4 chunk slots keeps two to three chunks (64-96 KiB per CU) in flight.
+//   * A chunk slot holds the RAW packed pair-rows of the workgroup's rows of A and B, 64-row block by block and plane
+//     by plane: 2 KiB = two pieces of 16 pair-rows x 64 bytes, each ONE contiguous KiB of the chunk-major T-layout
+//     and one LDS-DMA instruction.  The LDS side of such an instruction is lane-linear by construction; the global side
+//     is free, so lane (r, kg, mm) = 32 r + 16 kg + mm fetches granule 2 kg + r of pair-row mm: a lane (kg, m) of a
+//     consumer then finds samples 8 kg .. 8 kg + 8 of pair-row m in piece m >> 4 at slots 16 kg + (m & 15) and 32 + that,
+//     and each of its two ds_read_b128 touches every bank quad once per 16-lane group (conflict-free).
+//   * Both halves of every dword are used by the lane that reads it: MFMA tile 0 of a 64-row block takes its EVEN
+//     rows, tile 1 the ODD rows (A: the wave's two row tiles; B: tiles 2j and 2j+1 of the workgroup).  Eight v_perm
+//     unzip two granules into the two tiles' operands.  B tile g therefore holds rows 64 (g>>1) + 2 q + (g&1).
+//   * One workgroup barrier per chunk: before it every wave waits (counted vmcnt) for its own pieces of the NEXT
+//     chunk, after it the slot of the chunk consumed LAST is refilled.  The raw granules of chunk c+1 are read and
+//     unzipped beside the MFMAs of chunk c (software pipeline over registers), so the two waves of a SIMD, which the
+//     barrier keeps in step, do not both stand in front of an LDS latency at the same time.
+// No fp32 -> 16-bit conversion happens here: the savers stored the parts.  Bias gradient = row sums of A (v_dot2c).
+template <bool TWO>
+__device__ __forceinline__ void wg_dma(uint32_t voff, const void* gbase, uint32_t m0v) {
+  // one or two 1-KiB pieces of a section (the immediate offset advances the global and the LDS address alike)
+  uint32_t keep;
+  if (TWO)
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\t"
+        "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(m0v), "s"((uint64_t)gbase)
+        : "memory");
+  else
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(m0v), "s"((uint64_t)gbase)
+        : "memory");
+}
+
 template <int NW, int MG, int BT, int PREC>
 __global__ __launch_bounds__(64 * NW, 2) void k_wgrad(WgArgs a) {  // (2 waves per SIMD: <= 256 registers)
   constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
   constexpr int NPL = X3 ? 2 : 1;  // planes: high parts (, low parts)
   constexpr int CG = NW / MG;
-  constexpr int NTHR = 64 * NW;
   constexpr int A_ROWS = 64 * MG;
-  constexpr int B_ROWS_MAX = CG * BT * 32;
-  constexpr int NB = (B_ROWS_MAX * 2 + NTHR - 1) / NTHR;  // staged items (pair-row x 8 samples) per thread
-  __shared__ __attribute__((aligned(16))) char lds[2][2][B_ROWS_MAX * 64];  // [buffer][hi/lo][(tile,kstep,lane) x 16 B]
+  constexpr int NTB = CG * BT;          // 32-row MFMA tiles of B per workgroup
+  constexpr int NBB = (NTB + 1) / 2;    // 64-row blocks of B
+  constexpr int NBP = (BT + 1) / 2;     // blocks of B a wave reads
+  constexpr int NQ = (MG + NBB) * NPL;  // (block, plane) sections of a chunk slot, 2 KiB each
+  constexpr int SLOT = NQ * 2048;
+  constexpr int NSTAGE = 4;
+  constexpr int PAIRS = (NQ + NW - 1) / NW;  // sections a wave loads per chunk (two LDS-DMA instructions each)
+  static_assert(NW == 8 && (BT == 1 || BT % 2 == 0) && PAIRS <= 3 && NSTAGE * SLOT <= 160 * 1024, "k_wgrad geometry");
+  __shared__ __attribute__((aligned(1024))) char lds[NSTAGE * SLOT];
   const WgJob jb = a.job[blockIdx.y];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rg = wave % MG, cg = wave / MG;
   const int m = lane & 31, kg = lane >> 5;
   const int b_rows = jb.b_rows, b_pairs = b_rows >> 1;
+  const int nbb = (b_rows + 63) >> 6;  // blocks of B that exist (the last one may be half full: 32 direction rows)
   const int a_tot = jb.a_rows, rb = blockIdx.z;  // this workgroup's rows: [rb A_ROWS, (rb + 1) A_ROWS) of a_tot
-  const bool active = cg * BT * 32 < b_rows;
+  const int g0 = cg * BT;                        // the wave's first B tile
+  const bool active = (g0 >> 1) < nbb;
   const bool want_bias = jb.bpart && cg == 0;
   const int64_t t0 = (int64_t)blockIdx.x * a.T / a.nsplit, t1 = (int64_t)(blockIdx.x + 1) * a.T / a.nsplit;
-  const int64_t nchunk = (t1 - t0) * 4;
+  const int64_t nchunk = (t1 - t0) * (kTC / 16);
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
 
   f32x16 acc[2][BT];
 #pragma unroll
@@ -552,128 +610,138 @@ __global__ __launch_bounds__(64 * NW, 2) void k_wgrad(WgArgs a) {  // (2 waves p
       for (int r = 0; r < 16; ++r) acc[ti][bt][r] = 0.f;
   float bsum[2] = {0.f, 0.f};
 
-  // staging item q = it*512 + tid: pair-row PR = 16 (q>>6) + (q&15), sample group sg = (q>>4)&3
-  const int sg = (tid >> 4) & 3;
-  u32x4 braw[NB][NPL][2];
-  u32x4 araw[2][NPL][2];  // [k-step][plane][half]
-  // B raw of chunk ci+2 is requested as soon as the staging of chunk ci+1 has consumed the registers (bottom of
-  // iteration ci), A raw of chunk ci+1 as soon as chunk ci's fragments are unzipped (top): every load has a whole
-  // iteration (MFMA phase + staging) to land, at no register cost.
-  auto load_b = [&](int64_t ci) {
-    const int64_t t = t0 + (ci >> 2);
-    const int c = (int)(ci & 3);
+  // ---- loader side: this wave's sections q = wave + 8 j of every chunk
+  const int nq = (MG + nbb) * NPL;
+  const bool half_last = (b_pairs & 31) != 0;  // the last block of B holds 16 pair-rows: one piece
+  int my_inst = 0;                             // LDS-DMA instructions of this wave per chunk (wave-uniform)
 #pragma unroll
-    for (int it = 0; it < NB; ++it) {
-      const int PR = 16 * ((it * NTHR + tid) >> 6) + (tid & 15);
-      if (PR < b_pairs) {
+  for (int j = 0; j < PAIRS; ++j) {
+    const int q = wave + NW * j;
+    if (q < nq) my_inst += (half_last && q / NPL == MG + nbb - 1) ? 1 : 2;
+  }
+  const uint32_t voff = (uint32_t)(((lane & 15) * 4 + ((lane >> 4) & 1) * 2 + (lane >> 5)) * 16);
+  auto issue = [&](int64_t cj) {
+    const int64_t t = t0 + cj / (kTC / 16);
+    const int64_t c16 = cj % (kTC / 16);
+    const uint32_t slot = lds_base + (uint32_t)(cj % NSTAGE) * SLOT;
 #pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) {
-          const uint32_t* p = jb.B + ((t * 2 + pl) * b_pairs + PR) * kTC + 32 * c + 8 * sg;
-          braw[it][pl][0] = *reinterpret_cast<const u32x4*>(p);
-          braw[it][pl][1] = *reinterpret_cast<const u32x4*>(p + 4);
-        }
+    for (int j = 0; j < PAIRS; ++j) {
+      const int q = wave + NW * j;
+      if (q < nq) {
+        const int sec = q / NPL, pl = q % NPL;
+        const bool isA = sec < MG;
+        const uint32_t* base = isA ? jb.A : jb.B;
+        const int64_t pairs_tot = isA ? a_tot / 2 : b_pairs;
+        const int64_t pair0 = isA ? rb * (A_ROWS / 2) + sec * 32 : (sec - MG) * 32;
+        const uint32_t* g = base + (t * 2 + pl) * pairs_tot * kTC + (c16 * pairs_tot + pair0) * kTRow;
+        if (half_last && sec == MG + nbb - 1) wg_dma<false>(voff, g, slot + (uint32_t)q * 2048u);
+        else wg_dma<true>(voff, g, slot + (uint32_t)q * 2048u);
       }
     }
   };
-  auto load_a = [&](int64_t ci) {
-    const int64_t t = t0 + (ci >> 2);
-    const int c = (int)(ci & 3);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) {
-        // k order inside the 32-sample chunk: lane group kg takes samples [16 kg, 16 kg + 16) (8 per k-step), so its
-        // loads of a pair-row are 64 contiguous bytes per plane; the B staging below uses the same order
-        const uint32_t* p =
-            jb.A + ((t * 2 + pl) * (a_tot / 2) + rb * (A_ROWS / 2) + 32 * rg + m) * kTC + 32 * c + 16 * kg + 8 * ks;
-        araw[ks][pl][0] = *reinterpret_cast<const u32x4*>(p);
-        araw[ks][pl][1] = *reinterpret_cast<const u32x4*>(p + 4);
-      }
-  };
-  auto stage_b = [&](int buf) {
-#pragma unroll
-    for (int it = 0; it < NB; ++it) {
-      const int PR = 16 * ((it * NTHR + tid) >> 6) + (tid & 15);
-      if (PR < b_pairs) {
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) {
-          s16x8 ev, od;
-          if (pl == 1) unzip_rows(unscale_lo<F16 && X3>(braw[it][pl][0]), unscale_lo<F16 && X3>(braw[it][pl][1]), ev, od);
-          else unzip_rows(braw[it][pl][0], braw[it][pl][1], ev, od);
-          const int R = 2 * PR;  // rows R (even) and R + 1 (odd) sit next to each other in a tile's operand image
-          const int addr = ((((R >> 5) * 2 + (sg & 1)) * 64) + (sg >> 1) * 32 + (R & 31)) * 16;  // sg = 2 kg + ks
-          *reinterpret_cast<s16x8*>(&lds[buf][pl][addr]) = ev;
-          *reinterpret_cast<s16x8*>(&lds[buf][pl][addr + 16]) = od;
-        }
-      }
+  // own pieces of the oldest chunk in flight landed: vmcnt counts in issue order, NSTAGE - 2 younger chunks may stay
+  auto wait_counted = [&]() {
+    static_assert(NSTAGE == 4 && PAIRS <= 3, "the immediates below are 2 chunks x instructions per chunk");
+    switch (my_inst) {
+      case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+      default: break;
     }
   };
 
-  if (nchunk > 0) {
-    load_a(0);
-    load_b(0);
-    stage_b(0);
-    if (nchunk > 1) load_b(1);
-  }
-  __syncthreads();
-  for (int64_t ci = 0; ci < nchunk; ++ci) {
-    const int buf = (int)(ci & 1);
-    // this chunk's A operands: tile 0 = even rows, tile 1 = odd rows of the block (and the bias row sums)
-    Frag af[2][2];
+  const int lane_off = (m >> 4) * 1024 + (kg * 16 + (m & 15)) * 16;  // granules 2 kg, 2 kg + 1 (+512) of pair-row m
+  Frag af[2];    // current chunk: the wave's A rows, tile 0 (even rows) / tile 1 (odd rows)
+  Frag bfr[BT];  // ... its B tiles
+  for (int c = 0; c < NSTAGE - 1 && c < nchunk; ++c) issue(c);
+  for (int64_t ci = -1; ci < nchunk; ++ci) {
+    const bool more = ci + 1 < nchunk;
+    u32x4 rawA[NPL][2], rawB[NBP][NPL][2];
+    if (more) {
+      if (nchunk - 2 - ci >= NSTAGE - 2) wait_counted();
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last chunks: nothing younger was issued
+      asm volatile("s_barrier" ::: "memory");
+      if (ci + NSTAGE < nchunk) issue(ci + NSTAGE);  // into the slot of chunk ci, which every wave has left
+      const char* sl = lds + (int)((ci + 1) % NSTAGE) * SLOT + lane_off;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      unzip_rows(araw[ks][0][0], araw[ks][0][1], af[0][ks].hi, af[1][ks].hi);
-      if (X3) unzip_rows(unscale_lo<F16>(araw[ks][1][0]), unscale_lo<F16>(araw[ks][1][1]), af[0][ks].lo, af[1][ks].lo);
-    }
-    if (want_bias) {
+      for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
-      for (int ti = 0; ti < 2; ++ti)
+        for (int h = 0; h < 2; ++h) {
+          rawA[pl][h] = *reinterpret_cast<const u32x4*>(sl + (rg * NPL + pl) * 2048 + h * 512);
+          if (active) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          bsum[ti] = frag_sum<F16>(af[ti][ks].hi, bsum[ti]);
-          if (X3) bsum[ti] = frag_sum<F16>(af[ti][ks].lo, bsum[ti]);
+            for (int j = 0; j < NBP; ++j)
+              rawB[j][pl][h] = *reinterpret_cast<const u32x4*>(sl + ((MG + (g0 >> 1) + j) * NPL + pl) * 2048 + h * 512);
+          }
         }
+      }
     }
-    if (ci + 1 < nchunk) load_a(ci + 1);  // next chunk's A loads fly under the MFMAs and the staging
-    if (active) {
+    if (ci >= 0) {
+      if (want_bias) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+        for (int ti = 0; ti < 2; ++ti) {
+          bsum[ti] = frag_sum<F16>(af[ti].hi, bsum[ti]);
+          if (X3) bsum[ti] = frag_sum<F16>(af[ti].lo, bsum[ti]);
+        }
+      }
+      if (active) {
 #pragma unroll
-        for (int bt = 0; bt < BT; ++bt) {
-          const int addr = (((cg * BT + bt) * 2 + ks) * 64 + lane) * 16;
-          const s16x8 bh = *reinterpret_cast<const s16x8*>(&lds[buf][0][addr]);
-          s16x8 bl = bh;
-          if (X3) bl = *reinterpret_cast<const s16x8*>(&lds[buf][1][addr]);
+        for (int bt = 0; bt < BT; ++bt)
 #pragma unroll
           for (int ti = 0; ti < 2; ++ti) {
-            acc[ti][bt] = mfma32<F16>(af[ti][ks].hi, bh, acc[ti][bt]);
+            acc[ti][bt] = mfma32<F16>(af[ti].hi, bfr[bt].hi, acc[ti][bt]);
             if (X3) {
-              acc[ti][bt] = mfma32<F16>(af[ti][ks].lo, bh, acc[ti][bt]);
+              acc[ti][bt] = mfma32<F16>(af[ti].lo, bfr[bt].hi, acc[ti][bt]);
 #ifndef FSN_WGRAD_NOBLO  // experiment: drop the (dPre high) x (input low) product
-              acc[ti][bt] = mfma32<F16>(af[ti][ks].hi, bl, acc[ti][bt]);
+              acc[ti][bt] = mfma32<F16>(af[ti].hi, bfr[bt].lo, acc[ti][bt]);
 #endif
             }
           }
-        }
+      }
     }
-    if (ci + 1 < nchunk) stage_b(buf ^ 1);
-    if (ci + 2 < nchunk) load_b(ci + 2);
-    __syncthreads();
+    if (more) {
+      unzip_rows(rawA[0][0], rawA[0][1], af[0].hi, af[1].hi);
+      if (X3) unzip_rows(unscale_lo<F16>(rawA[NPL - 1][0]), unscale_lo<F16>(rawA[NPL - 1][1]), af[0].lo, af[1].lo);
+      if (active) {
+#pragma unroll
+        for (int j = 0; j < NBP; ++j) {
+          s16x8 ev, od, evl, odl;
+          unzip_rows(rawB[j][0][0], rawB[j][0][1], ev, od);
+          evl = ev; odl = od;
+          if (X3) unzip_rows(unscale_lo<F16>(rawB[j][NPL - 1][0]), unscale_lo<F16>(rawB[j][NPL - 1][1]), evl, odl);
+          if constexpr (BT == 1) {  // one tile per wave: the even or the odd rows of the block it shares with its neighbour
+            const bool odd = g0 & 1;
+            bfr[0].hi = odd ? od : ev;
+            bfr[0].lo = odd ? odl : evl;
+          } else {
+            bfr[2 * j].hi = ev; bfr[2 * j].lo = evl;
+            bfr[2 * j + 1].hi = od; bfr[2 * j + 1].lo = odl;
+          }
+        }
+      }
+    }
   }
   // partial block: C layout of the 32x32 tile: column = lane&31, tile row = (r&3) + 8 (r>>2) + 4 (lane>>5); tile ti's
-  // row q is row 2 q + ti of the wave's 64-row block
+  // row q is row 2 q + ti of the wave's 64-row block, B tile g's column q is row 64 (g>>1) + 2 q + (g&1) of B
   if (active) {
     float* part = jb.part + ((int64_t)blockIdx.x * a_tot + rb * A_ROWS) * b_rows;
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+    for (int bt = 0; bt < BT; ++bt) {
+      const int g = g0 + bt;
+      const int cc = 64 * (g >> 1) + 2 * m + (g & 1);
+      if (cc < b_rows) {
 #pragma unroll
-      for (int bt = 0; bt < BT; ++bt)
+        for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = 64 * rg + 2 * ((r & 3) + 8 * (r >> 2) + 4 * kg) + ti;
-          const int cc = (cg * BT + bt) * 32 + m;
-          part[(int64_t)row * b_rows + cc] = acc[ti][bt][r];
-        }
+          for (int r = 0; r < 16; ++r) {
+            const int row = 64 * rg + 2 * ((r & 3) + 8 * (r >> 2) + 4 * kg) + ti;
+            part[(int64_t)row * b_rows + cc] = acc[ti][bt][r];
+          }
+      }
+    }
   }
   if (want_bias) {
 #pragma unroll
@@ -733,8 +801,10 @@ __global__ void k_wgrad_reduce(RdArgs a) {
 
 // ------------------------------------------------------------------ head weights
 // dW_sigma[f] = sum_s dsigma_s h_{L-1}[f,s];  dW_rgb[c,f] = sum_s dz_c,s Bo[f,s];  biases = sums of dsigma / dz.
-// Wave w owns 2 NT pair-rows of h_{L-1} and NT pair-rows of Bo (packed T-layout: value = high part + low part);
-// lanes run along the samples (512-byte coalesced rows per plane).
+// Wave w owns 2 NT pair-rows of h_{L-1} and NT pair-rows of Bo (packed T-layout: value = high part + low part).
+// Four lanes per pair-row, four samples (one 16-byte granule) each: the wave's pair-rows of one 16-sample chunk are
+// one contiguous run of the chunk-major layout (1 KiB for 16 pair-rows); with fewer pair-rows per wave the lane groups
+// left over take the following chunks.
 struct HeadsArgs {
   const uint32_t *H, *Bo;
   const float* dhead;
@@ -746,81 +816,96 @@ struct HeadsArgs {
 template <int NT, int PREC>
 __global__ __launch_bounds__(kThreads) void k_heads_wgrad(HeadsArgs a) {
   constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
-  constexpr int D = 32 * NT, RS = 4 * NT, RR = 2 * NT;
-  typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+  constexpr int D = 32 * NT, PH = 2 * NT, PB = NT;     // pair-rows of H / Bo per wave
+  constexpr int CH = 16 / PH, CB = 16 / PB;             // chunks the wave's lanes cover side by side
+  constexpr int NCH = kTC / 16;
+  static_assert(PH <= 16 && 16 % PH == 0 && 16 % PB == 0 && NCH % CB == 0, "k_heads_wgrad geometry");
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t t0 = (int64_t)blockIdx.x * a.T / a.nsplit, t1 = (int64_t)(blockIdx.x + 1) * a.T / a.nsplit;
-  float accS[RS], accR[3][RR], accB[4] = {0.f, 0.f, 0.f, 0.f};
+  const int s4 = (lane & 3) * 4, idx = lane >> 2;
+  const int qh = idx % PH, ch = idx / PH, qb = idx % PB, cb = idx / PB;
+  float accS[2] = {0.f, 0.f}, accR[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, accB[4] = {0.f, 0.f, 0.f, 0.f};
+  // the two rows of a pair-row at four samples: v[row parity][sample]
+  auto load_pair = [&](const uint32_t* p, int64_t plane, float (&v)[2][4]) {
+    const u32x4 h = *reinterpret_cast<const u32x4*>(p);
+    u32x4 l = {0u, 0u, 0u, 0u};
+    if (X3) l = *reinterpret_cast<const u32x4*>(p + plane);
 #pragma unroll
-  for (int r = 0; r < RS; ++r) accS[r] = 0.f;
-#pragma unroll
-  for (int c = 0; c < 3; ++c)
-#pragma unroll
-    for (int r = 0; r < RR; ++r) accR[c][r] = 0.f;
-  // the two rows of pair-row q at samples 2 lane, 2 lane + 1: v[row parity][sample]
-  auto load_pair = [&](const uint32_t* p, int64_t plane, float (&v)[2][2]) {
-    const u32x2 h = *reinterpret_cast<const u32x2*>(p);
-    u32x2 l = {0u, 0u};
-    if (X3) l = *reinterpret_cast<const u32x2*>(p + plane);
-#pragma unroll
-    for (int sidx = 0; sidx < 2; ++sidx) {
-      v[0][sidx] = from_h<F16>((short)(h[sidx] & 0xffffu));
-      v[1][sidx] = from_h<F16>((short)(h[sidx] >> 16));
+    for (int i = 0; i < 4; ++i) {
+      v[0][i] = from_h<F16>((short)(h[i] & 0xffffu));
+      v[1][i] = from_h<F16>((short)(h[i] >> 16));
       if (X3) {  // (fp16: the low parts are stored scaled by 2^11)
         constexpr float IK = F16 ? 1.0f / kLoScaleF16 : 1.0f;
-        v[0][sidx] = __builtin_fmaf(from_h<F16>((short)(l[sidx] & 0xffffu)), IK, v[0][sidx]);
-        v[1][sidx] = __builtin_fmaf(from_h<F16>((short)(l[sidx] >> 16)), IK, v[1][sidx]);
+        v[0][i] = __builtin_fmaf(from_h<F16>((short)(l[i] & 0xffffu)), IK, v[0][i]);
+        v[1][i] = __builtin_fmaf(from_h<F16>((short)(l[i] >> 16)), IK, v[1][i]);
       }
     }
   };
   for (int64_t t = t0; t < t1; ++t) {
-    f32x2 dh[4];
+    const float* dht = a.dhead + t * 4 * kTC;
+    if (wave == 0) {  // biases: sums of d sigma / d z over the tile's samples
 #pragma unroll
-    for (int c = 0; c < 4; ++c) dh[c] = *reinterpret_cast<const f32x2*>(a.dhead + (t * 4 + c) * kTC + 2 * lane);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) accB[c] += dh[c][0] + dh[c][1];
-    const uint32_t* hp = a.H + (t * D + (RS / 2) * wave) * kTC + 2 * lane;
-#pragma unroll
-    for (int q = 0; q < RS / 2; ++q) {
-      float h[2][2];
-      load_pair(hp + q * kTC, (D / 2) * kTC, h);
-      accS[2 * q] += dh[3][0] * h[0][0] + dh[3][1] * h[0][1];
-      accS[2 * q + 1] += dh[3][0] * h[1][0] + dh[3][1] * h[1][1];
+      for (int c = 0; c < 4; ++c) {
+        const f32x2 d2 = *reinterpret_cast<const f32x2*>(dht + c * kTC + 2 * lane);
+        accB[c] += d2[0] + d2[1];
+      }
     }
-    const uint32_t* bp = a.Bo + (t * (D / 2) + (RR / 2) * wave) * kTC + 2 * lane;
+    const uint32_t* hp = a.H + t * D * kTC + (PH * wave + qh) * kTRow + s4;
 #pragma unroll
-    for (int q = 0; q < RR / 2; ++q) {
-      float b[2][2];
-      load_pair(bp + q * kTC, (D / 4) * kTC, b);
+    for (int c0 = 0; c0 < NCH; c0 += CH) {
+      const int c = c0 + ch;
+      const f32x4 ds = *reinterpret_cast<const f32x4*>(dht + 3 * kTC + 16 * c + s4);
+      float h[2][4];
+      load_pair(hp + (int64_t)c * (D / 2) * kTRow, (D / 2) * kTC, h);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        accR[c][2 * q] += dh[c][0] * b[0][0] + dh[c][1] * b[0][1];
-        accR[c][2 * q + 1] += dh[c][0] * b[1][0] + dh[c][1] * b[1][1];
+      for (int i = 0; i < 4; ++i) {
+        accS[0] += ds[i] * h[0][i];
+        accS[1] += ds[i] * h[1][i];
+      }
+    }
+    const uint32_t* bp = a.Bo + t * (D / 2) * kTC + (PB * wave + qb) * kTRow + s4;
+#pragma unroll
+    for (int c0 = 0; c0 < NCH; c0 += CB) {
+      const int c = c0 + cb;
+      float b[2][4];
+      load_pair(bp + (int64_t)c * (D / 4) * kTRow, (D / 4) * kTC, b);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const f32x4 dz = *reinterpret_cast<const f32x4*>(dht + k * kTC + 16 * c + s4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          accR[k][0] += dz[i] * b[0][i];
+          accR[k][1] += dz[i] * b[1][i];
+        }
       }
     }
   }
   float* out = a.hpart + (int64_t)blockIdx.x * (D + 3 * (D / 2) + 4);
-  auto wsum = [](float v) {
-#pragma unroll
-    for (int mm = 32; mm >= 1; mm >>= 1) v += __shfl_xor(v, mm, 64);
+  // lanes of one pair-row: the four sample granules (lane bits 0-1) and the chunk groups (lane bits above 2 + log2 P)
+  auto rsum = [&](float v, int P) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    for (int mm = 4 * P; mm < 64; mm <<= 1) v += __shfl_xor(v, mm, 64);
     return v;
   };
 #pragma unroll
-  for (int r = 0; r < RS; ++r) {
-    const float v = wsum(accS[r]);
-    if (lane == 0) out[RS * wave + r] = v;
+  for (int par = 0; par < 2; ++par) {
+    const float v = rsum(accS[par], PH);
+    if ((lane & 3) == 0 && ch == 0) out[2 * PH * wave + 2 * qh + par] = v;
   }
 #pragma unroll
-  for (int c = 0; c < 3; ++c)
+  for (int k = 0; k < 3; ++k)
 #pragma unroll
-    for (int r = 0; r < RR; ++r) {
-      const float v = wsum(accR[c][r]);
-      if (lane == 0) out[D + c * (D / 2) + RR * wave + r] = v;
+    for (int par = 0; par < 2; ++par) {
+      const float v = rsum(accR[k][par], PB);
+      if ((lane & 3) == 0 && cb == 0) out[D + k * (D / 2) + 2 * PB * wave + 2 * qb + par] = v;
     }
   if (wave == 0) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const float v = wsum(accB[c]);
+      float v = accB[c];
+#pragma unroll
+      for (int mm = 32; mm >= 1; mm >>= 1) v += __shfl_xor(v, mm, 64);
       if (lane == 0) out[D + 3 * (D / 2) + c] = v;
     }
   }

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-opt", action="store_true", help="skip the optimizer update (timing experiments on kernels whose gradients are not meaningful)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -40,7 +41,8 @@ def main():
         loss = torch.nn.functional.mse_loss(rgb, gt)
         loss.backward()
         shard.allreduce_grads(m.parameters())
-        opt.step()
+        if not a.no_opt:
+            opt.step()
         return loss
 
     for _ in range(a.warmup):
