@@ -32,6 +32,8 @@
 // x3 modes: pinned one-unit-ahead LDS prefetch of the A operands (mlp_dev.hpp).  +6 % on these kernels; the fused
 // render kernel keeps the compiler's own read placement (with its larger live state the pinned form spills more).
 #define FSN_X3_PF1
+#include <type_traits>
+
 #include "mlp_dev.hpp"
 #include "mlp_layout.hpp"
 #include "train_internal.hpp"
@@ -486,6 +488,9 @@ __device__ __forceinline__ f32x16 mfma32(const s16x8& a, const s16x8& b, const f
 // case it is the value rounds 1-2 stored).  Gradients are asserted to 2e-4 of a tensor's largest entry, far above that.
 template <bool F16X3>
 __device__ __forceinline__ u32x4 unscale_lo(u32x4 w) {
+#ifdef FSN_WGRAD_NOUNZIP
+  return w;
+#endif
   if constexpr (F16X3) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) asm("v_pk_mul_f16 %0, %0, %1" : "+v"(w[i]) : "s"(0x10001000u));  // 2^-11 | 2^-11
@@ -495,6 +500,11 @@ __device__ __forceinline__ u32x4 unscale_lo(u32x4 w) {
 
 // the two rows of a pair-row out of 8 packed dwords (8 samples): low halves -> row 2q, high halves -> row 2q+1
 __device__ __forceinline__ void unzip_rows(const u32x4& d0, const u32x4& d1, s16x8& even, s16x8& odd) {
+#ifdef FSN_WGRAD_NOUNZIP  // timing experiment: the k_wgrad stream without its VALU work (results are garbage)
+  even = __builtin_bit_cast(s16x8, d0);
+  odd = __builtin_bit_cast(s16x8, d1);
+  return;
+#endif
   u32x4 e, o;
   e[0] = __builtin_amdgcn_perm(d0[1], d0[0], 0x05040100u); o[0] = __builtin_amdgcn_perm(d0[1], d0[0], 0x07060302u);
   e[1] = __builtin_amdgcn_perm(d0[3], d0[2], 0x05040100u); o[1] = __builtin_amdgcn_perm(d0[3], d0[2], 0x07060302u);
@@ -656,73 +666,117 @@ __global__ __launch_bounds__(64 * NW, 2) void k_wgrad(WgArgs a) {  // (2 waves p
   const int lane_off = (m >> 4) * 1024 + (kg * 16 + (m & 15)) * 16;  // granules 2 kg, 2 kg + 1 (+512) of pair-row m
   Frag af[2];    // current chunk: the wave's A rows, tile 0 (even rows) / tile 1 (odd rows)
   Frag bfr[BT];  // ... its B tiles
-  for (int c = 0; c < NSTAGE - 1 && c < nchunk; ++c) issue(c);
-  for (int64_t ci = -1; ci < nchunk; ++ci) {
-    const bool more = ci + 1 < nchunk;
-    u32x4 rawA[NPL][2], rawB[NBP][NPL][2];
-    if (more) {
-      if (nchunk - 2 - ci >= NSTAGE - 2) wait_counted();
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last chunks: nothing younger was issued
-      asm volatile("s_barrier" ::: "memory");
-      if (ci + NSTAGE < nchunk) issue(ci + NSTAGE);  // into the slot of chunk ci, which every wave has left
-      const char* sl = lds + (int)((ci + 1) % NSTAGE) * SLOT + lane_off;
+  u32x4 rawA[NPL][2], rawB[NBP][NPL][2];
+  // One step = [wait + barrier: chunk ci+1 landed, slot of chunk ci free] [refill that slot] [raw reads of chunk ci+1]
+  // [MFMAs of chunk ci] [unzip chunk ci+1].  ACT / BIAS (wave-uniform) are compile-time inside the loops so that the
+  // steady-state step is ONE basic block after its scalar head: the scheduler is then told to place the ~4.5 VALU
+  // instructions per MFMA of the unzip (v_perm, the 2^-11 of the low parts, row sums) and the 12 reads BETWEEN the 24
+  // MFMAs - left alone it emits the MFMAs back to back and the unzip after them, and since the barrier keeps the two
+  // waves of a SIMD in step both then leave the matrix pipe idle together.
+  auto reads = [&](int64_t cj, auto ACT) {
+    const char* sl = lds + (int)(cj % NSTAGE) * SLOT + lane_off;
 #pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) {
+    for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          rawA[pl][h] = *reinterpret_cast<const u32x4*>(sl + (rg * NPL + pl) * 2048 + h * 512);
-          if (active) {
+      for (int h = 0; h < 2; ++h) {
+        rawA[pl][h] = *reinterpret_cast<const u32x4*>(sl + (rg * NPL + pl) * 2048 + h * 512);
+        if constexpr (decltype(ACT)::value) {
 #pragma unroll
-            for (int j = 0; j < NBP; ++j)
-              rawB[j][pl][h] = *reinterpret_cast<const u32x4*>(sl + ((MG + (g0 >> 1) + j) * NPL + pl) * 2048 + h * 512);
-          }
+          for (int jj = 0; jj < NBP; ++jj)
+            rawB[jj][pl][h] = *reinterpret_cast<const u32x4*>(sl + ((MG + (g0 >> 1) + jj) * NPL + pl) * 2048 + h * 512);
         }
       }
+  };
+  auto mfmas = [&](auto ACT, auto BIAS) {
+    if constexpr (decltype(BIAS)::value) {
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti) {
+        bsum[ti] = frag_sum<F16>(af[ti].hi, bsum[ti]);
+        if (X3) bsum[ti] = frag_sum<F16>(af[ti].lo, bsum[ti]);
+      }
     }
-    if (ci >= 0) {
-      if (want_bias) {
+    if constexpr (decltype(ACT)::value) {
+#pragma unroll
+      for (int bt = 0; bt < BT; ++bt)
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
-          bsum[ti] = frag_sum<F16>(af[ti].hi, bsum[ti]);
-          if (X3) bsum[ti] = frag_sum<F16>(af[ti].lo, bsum[ti]);
-        }
-      }
-      if (active) {
-#pragma unroll
-        for (int bt = 0; bt < BT; ++bt)
-#pragma unroll
-          for (int ti = 0; ti < 2; ++ti) {
-            acc[ti][bt] = mfma32<F16>(af[ti].hi, bfr[bt].hi, acc[ti][bt]);
-            if (X3) {
-              acc[ti][bt] = mfma32<F16>(af[ti].lo, bfr[bt].hi, acc[ti][bt]);
+          acc[ti][bt] = mfma32<F16>(af[ti].hi, bfr[bt].hi, acc[ti][bt]);
+          if (X3) {
+            acc[ti][bt] = mfma32<F16>(af[ti].lo, bfr[bt].hi, acc[ti][bt]);
 #ifndef FSN_WGRAD_NOBLO  // experiment: drop the (dPre high) x (input low) product
-              acc[ti][bt] = mfma32<F16>(af[ti].hi, bfr[bt].lo, acc[ti][bt]);
+            acc[ti][bt] = mfma32<F16>(af[ti].hi, bfr[bt].lo, acc[ti][bt]);
 #endif
-            }
           }
-      }
+        }
     }
-    if (more) {
-      unzip_rows(rawA[0][0], rawA[0][1], af[0].hi, af[1].hi);
-      if (X3) unzip_rows(unscale_lo<F16>(rawA[NPL - 1][0]), unscale_lo<F16>(rawA[NPL - 1][1]), af[0].lo, af[1].lo);
-      if (active) {
+  };
+  auto unzip = [&](auto ACT) {
+    unzip_rows(rawA[0][0], rawA[0][1], af[0].hi, af[1].hi);
+    if (X3) unzip_rows(unscale_lo<F16>(rawA[NPL - 1][0]), unscale_lo<F16>(rawA[NPL - 1][1]), af[0].lo, af[1].lo);
+    if constexpr (decltype(ACT)::value) {
 #pragma unroll
-        for (int j = 0; j < NBP; ++j) {
-          s16x8 ev, od, evl, odl;
-          unzip_rows(rawB[j][0][0], rawB[j][0][1], ev, od);
-          evl = ev; odl = od;
-          if (X3) unzip_rows(unscale_lo<F16>(rawB[j][NPL - 1][0]), unscale_lo<F16>(rawB[j][NPL - 1][1]), evl, odl);
-          if constexpr (BT == 1) {  // one tile per wave: the even or the odd rows of the block it shares with its neighbour
-            const bool odd = g0 & 1;
-            bfr[0].hi = odd ? od : ev;
-            bfr[0].lo = odd ? odl : evl;
-          } else {
-            bfr[2 * j].hi = ev; bfr[2 * j].lo = evl;
-            bfr[2 * j + 1].hi = od; bfr[2 * j + 1].lo = odl;
-          }
+      for (int jj = 0; jj < NBP; ++jj) {
+        s16x8 ev, od, evl, odl;
+        unzip_rows(rawB[jj][0][0], rawB[jj][0][1], ev, od);
+        evl = ev; odl = od;
+        if (X3) unzip_rows(unscale_lo<F16>(rawB[jj][NPL - 1][0]), unscale_lo<F16>(rawB[jj][NPL - 1][1]), evl, odl);
+        if constexpr (BT == 1) {  // one tile per wave: the even or the odd rows of the block it shares with its neighbour
+          const bool odd = g0 & 1;
+          bfr[0].hi = odd ? od : ev;
+          bfr[0].lo = odd ? odl : evl;
+        } else {
+          bfr[2 * jj].hi = ev; bfr[2 * jj].lo = evl;
+          bfr[2 * jj + 1].hi = od; bfr[2 * jj + 1].lo = odl;
         }
       }
     }
+  };
+  auto run = [&](auto ACT, auto BIAS) {
+    constexpr bool kAct = decltype(ACT)::value;
+    auto edge_step = [&](int64_t ci) {  // first and last steps: any of the parts may be missing
+      const bool more = ci + 1 < nchunk;
+      if (more) {
+        if (nchunk - 2 - ci >= NSTAGE - 2) wait_counted();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last chunks: nothing younger was issued
+        asm volatile("s_barrier" ::: "memory");
+        if (ci + NSTAGE < nchunk) issue(ci + NSTAGE);  // into the slot of chunk ci, which every wave has left
+        reads(ci + 1, ACT);
+      }
+      if (ci >= 0) mfmas(ACT, BIAS);
+      if (more) unzip(ACT);
+    };
+    const int64_t steady_end = nchunk - NSTAGE;  // steps [0, steady_end): every part present
+    edge_step(-1);
+    for (int64_t ci = 0; ci < steady_end; ++ci) {
+      wait_counted();
+      asm volatile("s_barrier" ::: "memory");
+      issue(ci + NSTAGE);
+      __builtin_amdgcn_sched_barrier(0);
+      reads(ci + 1, ACT);
+      mfmas(ACT, BIAS);
+      unzip(ACT);
+      if constexpr (kAct) {
+        constexpr int NM = 2 * BT * (X3 ? 3 : 1);
+        constexpr int NR = 2 * NPL * (1 + NBP);
+#pragma unroll
+        for (int k = 0; k < NM; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // one MFMA
+          if (k < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one raw read of the next chunk
+          __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);              // its share of the VALU work
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int64_t ci = steady_end < 0 ? 0 : steady_end; ci < nchunk; ++ci) edge_step(ci);
+  };
+  using T1 = std::true_type;
+  using T0 = std::false_type;
+  for (int c = 0; c < NSTAGE - 1 && c < nchunk; ++c) issue(c);
+  if (active) {
+    if (want_bias) run(T1{}, T1{});
+    else run(T1{}, T0{});
+  } else {
+    run(T0{}, T0{});
   }
   // partial block: C layout of the 32x32 tile: column = lane&31, tile row = (r&3) + 8 (r>>2) + 4 (lane>>5); tile ti's
   // row q is row 2 q + ti of the wave's 64-row block, B tile g's column q is row 64 (g>>1) + 2 q + (g&1) of B
