@@ -88,10 +88,13 @@ constexpr int kGldsPerWave = kPhaseBytes / 1024 / kLoaders;  // 1-KiB LDS-DMA in
 constexpr int kRingBytes = kNSlot * kPhaseBytes;
 constexpr int kAuxCapFloats = 3456;  // LDS reserved per network for biases / heads (8x256 needs 3392)
 constexpr int kTileCols = 128;       // samples per workgroup tile = columns of a T-layout tile (train_fused.hip)
-constexpr int kTRow = 16;            // T-layout: dwords between consecutive pair-rows of one 16-sample chunk
-// T-layout (train_fused.hip) of a saved matrix with 2 P rows, per 128-sample tile and plane: [chunk of 16 samples][P
-// pair-rows][16 samples] dwords.  Offset of (pair-row pr, sample s of the tile) inside the plane:
-__host__ __device__ constexpr int64_t t_layout_off(int P, int pr, int s) { return (int64_t)(s >> 4) * P * kTRow + pr * kTRow + (s & 15); }
+constexpr int kTRow = 16;            // T-layout: samples of a chunk (consecutive pair-rows lie kTRow x NPL dwords apart)
+// T-layout (train_fused.hip) of a saved matrix with 2 P rows, per 128-sample tile: [chunk of 16 samples][P pair-rows]
+// [16 samples][NPL parts] dwords, NPL = 2 in the x3 modes (high part, low part side by side), 1 in the single-pass
+// modes.  Offset of the first part of (pair-row pr, sample s of the tile) inside the tile's block of 2 P x 128 dwords:
+__host__ __device__ constexpr int64_t t_layout_off(int NPL, int P, int pr, int s) {
+  return (((int64_t)(s >> 4) * P + pr) * kTRow + (s & 15)) * NPL;
+}
 
 struct Frag {  // one k-step (32 features x 16 samples) of activations as MFMA B operand
   s16x8 hi, lo;
@@ -484,15 +487,16 @@ __device__ __forceinline__ void encode(float x0, float x1, float x2, int n_freqs
   for (int k = 0; k < NKS; ++k) split_store<F16, X3>(&v[8 * k], out[k]);
   if constexpr (SAVE) {
     // packed T-layout (train_fused.hip): slots (k, 2i), (k, 2i+1) are rows 32k + 8g + 2i, +1 = pair-row 16k + 4g + i;
-    // `save` = this lane's sample at pair-row 4g of the high-part plane, the low-part plane 16 NKS x 128 dwords further
+    // `save` = this lane's sample at pair-row 4g (t_layout_off); x3: the two parts of a pair as one 8-byte store
     typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+    typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 #pragma unroll
     for (int k = 0; k < NKS; ++k) {
       const u32x4 h = __builtin_bit_cast(u32x4, out[k].hi), l = __builtin_bit_cast(u32x4, out[k].lo);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        __builtin_nontemporal_store(h[i], save + (16 * k + i) * kTRow);
-        if (X3) __builtin_nontemporal_store(l[i], save + 16 * NKS * kTileCols + (16 * k + i) * kTRow);
+        if (X3) __builtin_nontemporal_store((u32x2){h[i], l[i]}, reinterpret_cast<u32x2*>(save + (16 * k + i) * kTRow * 2));
+        else __builtin_nontemporal_store(h[i], save + (16 * k + i) * kTRow);
       }
     }
   }
@@ -636,14 +640,14 @@ __device__ __forceinline__ void pair_epilogue(const NetDev& net, int tp, const f
 #endif
       // value = main + 2^-11 x corrections (fp16 modes: exact power-of-two unscaling inside the fma); bf16: scale 1
       constexpr float IK = F16 ? 1.0f / kLoScaleF16 : 1.0f;
-      typedef __attribute__((ext_vector_type(2))) float f32x2;
-      const f32x2 ik2 = {IK, IK};
-#ifdef FSN_EPI_SCALAR_FMA  // timing experiment: eight v_fma_f32 in place of four v_pk_fma_f32
+#ifndef FSN_EPI_PK_FMA
+      // eight v_fma_f32: measured 0.6 % faster on the frame than four v_pk_fma_f32 (418.7 -> 416.2 ms), as
+      // MI355X_MICROARCH.md prices packed fp32 VALU beside MFMAs
 #pragma unroll
       for (int j = 0; j < 4; ++j) { v[j] = __builtin_fmaf(cor0[j], IK, acc0[j]); v[4 + j] = __builtin_fmaf(cor1[j], IK, acc1[j]); }
-      (void)ik2;
-      if constexpr (false)
-#endif
+#else
+      typedef __attribute__((ext_vector_type(2))) float f32x2;
+      const f32x2 ik2 = {IK, IK};
 #pragma unroll
       for (int j = 0; j < 4; j += 2) {  // v_pk_fma_f32: two values per instruction
         const f32x2 a0 = {acc0[j], acc0[j + 1]}, c0 = {cor0[j], cor0[j + 1]};
@@ -652,6 +656,7 @@ __device__ __forceinline__ void pair_epilogue(const NetDev& net, int tp, const f
         v[j] = r0[0]; v[j + 1] = r0[1];
         v[4 + j] = r1[0]; v[4 + j + 1] = r1[1];
       }
+#endif
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) { v[j] = acc0[j]; v[4 + j] = acc1[j]; }

@@ -13,16 +13,19 @@
 //   k_heads_wgrad : sigma / rgb head weights (1 and 3 output rows): HBM-bound row dot products.
 //
 // "Packed T-layout" of every saved matrix with R rows (features): tiles of 128 samples (one workgroup tile),
-// [tile][plane][chunk of 16 samples][R/2 pair-rows][16 samples] x 32 bit (mlp_dev.hpp, t_layout_off).  Plane 0 holds
-// the 16-bit HIGH parts, plane 1 the LOW parts (x3 modes only) of the value in the mode's 16-bit format; dword (q, s) =
-// part(row 2q, s) | part(row 2q+1, s) << 16.  These are the words the forward / backward epilogues form anyway for the
-// next GEMM's B operand (a packed pair of neighbouring features of one sample), so saving costs the stores only - and
-// the weight-gradient GEMM, whose contraction runs along the samples, has both rows' MFMA operands after four
-// v_perm_b32 each, instead of splitting fp32 values itself.  Same bytes as fp32 in the x3 modes, half in the
-// single-pass modes.  Chunk-major inside a tile (round 3; rounds 1-2: [pair-row][128 samples]): a wave of the forward /
-// backward kernels owns 16 samples, so its epilogue stores of neighbouring pair-rows are now neighbours in memory
-// (64-byte runs 64 bytes apart instead of 512), and what the wgrad kernels consume per k-step - all rows of 16 samples
-// - is ONE contiguous run per plane (8 KiB for 256 rows) instead of 64 bytes out of every 512.
+// [tile][chunk of 16 samples][R/2 pair-rows][16 samples][parts] x 32 bit (mlp_dev.hpp, t_layout_off).  A dword packs
+// one 16-bit part of two neighbouring rows: part(row 2q, s) | part(row 2q+1, s) << 16; the x3 modes keep the HIGH and
+// the LOW part of the value (in the mode's 16-bit format) side by side, the single-pass modes only have the first.
+// These are the words the forward / backward epilogues form anyway for the next GEMM's B operand (a packed pair of
+// neighbouring features of one sample), so saving costs the stores only - and the weight-gradient GEMM, whose
+// contraction runs along the samples, has both rows' MFMA operands after four v_perm_b32 each, instead of splitting
+// fp32 values itself.  Same bytes as fp32 in the x3 modes, half in the single-pass modes.
+// Round 3 changed the order inside a tile twice (rounds 1-2: [plane][pair-row][128 samples]):
+//   * chunk-major: a wave of the forward / backward kernels owns 16 samples, so its epilogue stores of neighbouring
+//     pair-rows are neighbours in memory, and what the wgrad kernels consume per k-step - all rows of 16 samples - is
+//     ONE contiguous run (16 KiB for 256 rows) instead of 64 bytes out of every 512;
+//   * parts side by side: a lane stores the two parts of a pair as one 8-byte store (the savers cost 0.5-0.6 ms in
+//     each of the two kernels, per instruction as much as per byte: DESIGN.md 6).
 //
 // Precision: as the forward, split 16-bit x 3 passes with fp32 accumulation.  In the fp16 modes d(out) is
 // multiplied by a power-of-two `grad_scale` on entry (and the result divided by it in the reduce) so that the
@@ -126,16 +129,20 @@ static int make_fused_layout(const fsn_mlp_desc& d, int prec, int64_t n, FusedLa
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 // Store the 16-bit parts of output pair tp (accumulator order: dword i of a part = rows 32 tp + 16 (i>>1) + 4 g +
-// 2 (i&1), +1 = pair-row 16 tp + 8 (i>>1) + 2 g + (i&1)).  p: this lane's sample at pair-row 2g of the high-part
-// plane of its tile (t_layout_off); plane: dwords between the two planes (R/2 x 128).
+// 2 (i&1), +1 = pair-row 16 tp + 8 (i>>1) + 2 g + (i&1)).  p: this lane's sample at pair-row 2g of its tile
+// (t_layout_off).
 template <bool X3>
-__device__ __forceinline__ void store_pair_parts(uint32_t* p, int64_t plane, int tp, const Frag& o) {
+__device__ __forceinline__ void store_pair_parts(uint32_t* p, int tp, const Frag& o) {
+  typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
   const u32x4 h = __builtin_bit_cast(u32x4, o.hi), l = __builtin_bit_cast(u32x4, o.lo);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    uint32_t* q = p + (16 * tp + 8 * (i >> 1) + (i & 1)) * kTRow;
-    FSN_STREAM_STORE(h[i], q);
-    if (X3) FSN_STREAM_STORE(l[i], q + plane);
+    const int pr = 16 * tp + 8 * (i >> 1) + (i & 1);
+#ifdef FSN_ABL_SAVE_NONE  // timing experiment: no saved parts at all
+    continue;
+#endif
+    if (X3) FSN_STREAM_STORE(((u32x2){h[i], l[i]}), reinterpret_cast<u32x2*>(p + pr * kTRow * 2));
+    else FSN_STREAM_STORE(h[i], p + pr * kTRow);
   }
 }
 
@@ -147,8 +154,7 @@ struct FwdSaver {
   struct Hook {
     static constexpr bool kZeroInit = false;
     static constexpr bool kPacked = true;
-    uint32_t* p;    // this lane's column at pair-row 2g, high-part plane
-    int64_t plane;  // dwords to the low-part plane
+    uint32_t* p;    // this lane's sample at pair-row 2g of the layer's tile
     uint8_t* mk;    // this lane's 8 mask bytes (one per output pair), or null (layer without activation)
     __device__ __forceinline__ void pre(int) {}
     __device__ __forceinline__ void post(int tp, float (&v)[8]) {
@@ -160,19 +166,19 @@ struct FwdSaver {
       }
     }
     template <bool X3>
-    __device__ __forceinline__ void store(int tp, const Frag& o) { store_pair_parts<X3>(p, plane, tp, o); }
+    __device__ __forceinline__ void store(int tp, const Frag& o) { store_pair_parts<X3>(p, tp, o); }
   };
   uint32_t* h0;  // this lane's column, pair-row 2g, of H_0's tile
-  int64_t hstride, hplane, boplane;
+  int64_t hstride;
   uint32_t *bo, *pe, *de;
   uint32_t* mk0;  // this lane's mask words of layer 0
   int64_t mstride;
   int n_layers;
   __device__ __forceinline__ Hook hidden(int l) const {
-    return Hook{h0 + l * hstride, hplane, l < n_layers ? reinterpret_cast<uint8_t*>(mk0 + l * mstride) : nullptr};
+    return Hook{h0 + l * hstride, l < n_layers ? reinterpret_cast<uint8_t*>(mk0 + l * mstride) : nullptr};
   }
   __device__ __forceinline__ Hook branch() const {
-    return Hook{bo, boplane, reinterpret_cast<uint8_t*>(mk0 + n_layers * mstride)};
+    return Hook{bo, reinterpret_cast<uint8_t*>(mk0 + n_layers * mstride)};
   }
   __device__ __forceinline__ uint32_t* enc_pos(int) const { return pe; }
   __device__ __forceinline__ uint32_t* enc_dir(int) const { return de; }
@@ -236,13 +242,12 @@ __global__ __launch_bounds__(kThreads) void k_train_fwd(TrainFwdArgs a) {
     const TileSrcT src{in_lds + col * 6};
     FwdSaver sv;
     uint32_t* wsu = reinterpret_cast<uint32_t*>(a.ws);
-    sv.h0 = wsu + a.off_h + tile * D * kTC + t_layout_off(D / 2, 2 * g, col);
+    constexpr int NPL = (PREC & 1) == 0 ? 2 : 1;
+    sv.h0 = wsu + a.off_h + tile * D * kTC + t_layout_off(NPL, D / 2, 2 * g, col);
     sv.hstride = a.h_stride;
-    sv.hplane = (D / 2) * kTC;
-    sv.bo = wsu + a.off_bo + tile * (D / 2) * kTC + t_layout_off(D / 4, 2 * g, col);
-    sv.boplane = (D / 4) * kTC;
-    sv.pe = wsu + a.off_pe + tile * 64 * kTC + t_layout_off(32, 4 * g, col);
-    sv.de = wsu + a.off_de + tile * 32 * kTC + t_layout_off(16, 4 * g, col);
+    sv.bo = wsu + a.off_bo + tile * (D / 2) * kTC + t_layout_off(NPL, D / 4, 2 * g, col);
+    sv.pe = wsu + a.off_pe + tile * 64 * kTC + t_layout_off(NPL, 32, 4 * g, col);
+    sv.de = wsu + a.off_de + tile * 32 * kTC + t_layout_off(NPL, 16, 4 * g, col);
     sv.mk0 = reinterpret_cast<uint32_t*>(a.ws + a.off_mask) + ((tile * 4 + g) * kTC + col) * 2;
     sv.mstride = a.mask_stride;
     sv.n_layers = net.n_layers;
@@ -303,12 +308,11 @@ __global__ void k_pack_bwd(BwdPackArgs a, char* __restrict__ stream, int64_t n_p
 struct BwdStoreHook {
   static constexpr bool kZeroInit = true;
   static constexpr bool kPacked = true;
-  uint32_t* d;  // this lane's column at pair-row 2g of the gradient's high-part plane
-  int64_t plane;
+  uint32_t* d;  // this lane's sample at pair-row 2g of the gradient's tile
   __device__ __forceinline__ void pre(int) {}
   __device__ __forceinline__ void post(int, float (&)[8]) {}
   template <bool X3>
-  __device__ __forceinline__ void store(int tp, const Frag& o) { store_pair_parts<X3>(d, plane, tp, o); }
+  __device__ __forceinline__ void store(int tp, const Frag& o) { store_pair_parts<X3>(d, tp, o); }
 };
 
 template <bool ADD_SIGMA>
@@ -317,7 +321,6 @@ struct BwdMaskHook {
   static constexpr bool kPacked = true;
   uint32_t b0, b1;    // sign bits of the layer whose pre-activation gradient this is (FwdSaver::Hook)
   uint32_t* d;        // dPre destination (as BwdStoreHook)
-  int64_t plane;
   float dsig;         // d sigma of this lane's sample
   const float* wsig;  // LDS: w_sigma + 4g
   __device__ __forceinline__ void pre(int) {}
@@ -336,7 +339,7 @@ struct BwdMaskHook {
     for (int j = 0; j < 8; ++j) v[j] = ((bits >> j) & 1u) ? v[j] : 0.f;
   }
   template <bool X3>
-  __device__ __forceinline__ void store(int tp, const Frag& o) { store_pair_parts<X3>(d, plane, tp, o); }
+  __device__ __forceinline__ void store(int tp, const Frag& o) { store_pair_parts<X3>(d, tp, o); }
 };
 
 struct TrainBwdArgs {
@@ -387,9 +390,9 @@ __global__ __launch_bounds__(kThreads) void k_train_bwd(TrainBwdArgs a) {
       dh[0] = dz[0]; dh[kTC] = dz[1]; dh[2 * kTC] = dz[2]; dh[3 * kTC] = dsig;
     }
     uint32_t* wsu = reinterpret_cast<uint32_t*>(a.ws);
-    const int64_t lane_off = tile * D * kTC + t_layout_off(D / 2, 2 * g, col);          // pair-row 2g, high-part plane, of a D-row tile
-    const int64_t lane_off_h = tile * (D / 2) * kTC + t_layout_off(D / 4, 2 * g, col);  // ... of a D/2-row tile
-    constexpr int64_t planeD = (D / 2) * kTC, planeH = (D / 4) * kTC;
+    constexpr int NPL = X3 ? 2 : 1;
+    const int64_t lane_off = tile * D * kTC + t_layout_off(NPL, D / 2, 2 * g, col);          // pair-row 2g of a D-row tile
+    const int64_t lane_off_h = tile * (D / 2) * kTC + t_layout_off(NPL, D / 4, 2 * g, col);  // ... of a D/2-row tile
     Frag A[NT], B[NT];
     const uint32_t* mk = reinterpret_cast<const uint32_t*>(a.ws + a.off_mask) + ((tile * 4 + g) * kTC + col) * 2;
     {  // branch output: d Bo = W_rgb^T dz, masked by Bo > 0 (models.py:133-134), VALU
@@ -411,11 +414,11 @@ __global__ __launch_bounds__(kThreads) void k_train_bwd(TrainBwdArgs a) {
           }
         }
         split_store<F16, X3>(v, B[ks]);
-        store_pair_parts<X3>(dbo, planeH, ks, B[ks]);
+        store_pair_parts<X3>(dbo, ks, B[ks]);
       }
     }
     {  // d feat = W_branch[:, :D]^T dBo  -> "dPre" of the connection (no activation, models.py:130)
-      BwdStoreHook hk{wsu + a.off_dp + L * a.h_stride + lane_off, planeD};
+      BwdStoreHook hk{wsu + a.off_dp + L * a.h_stride + lane_off};
       gemm_layer<PREC, NT, NT / 2, 0, EPI_CVT>(st, net, 0, B, none, A, heads, ring, g, hk);
     }
     {  // d h_{L-1} = W_conn^T d feat + d sigma w_sigma, masked by h_{L-1} > 0
@@ -423,7 +426,6 @@ __global__ __launch_bounds__(kThreads) void k_train_bwd(TrainBwdArgs a) {
       hk.b0 = mk[(L - 1) * a.mask_stride];
       hk.b1 = mk[(L - 1) * a.mask_stride + 1];
       hk.d = wsu + a.off_dp + (L - 1) * a.h_stride + lane_off;
-      hk.plane = planeD;
       hk.dsig = dsig;
       hk.wsig = net.aux + (L + 2) * D + 4 * g;
       gemm_layer<PREC, NT, NT, 0, EPI_CVT>(st, net, 0, A, none, B, heads, ring, g, hk);
@@ -435,16 +437,14 @@ __global__ __launch_bounds__(kThreads) void k_train_bwd(TrainBwdArgs a) {
         hk.b0 = mk[(l - 1) * a.mask_stride];
         hk.b1 = mk[(l - 1) * a.mask_stride + 1];
         hk.d = wsu + a.off_dp + (l - 1) * a.h_stride + lane_off;
-        hk.plane = planeD;
-        gemm_layer<PREC, NT, NT, 0, EPI_CVT>(st, net, 0, B, none, A, heads, ring, g, hk);
+          gemm_layer<PREC, NT, NT, 0, EPI_CVT>(st, net, 0, B, none, A, heads, ring, g, hk);
       }
       if (l - 1 >= 1) {
         BwdMaskHook<false> hk;
         hk.b0 = mk[(l - 2) * a.mask_stride];
         hk.b1 = mk[(l - 2) * a.mask_stride + 1];
         hk.d = wsu + a.off_dp + (l - 2) * a.h_stride + lane_off;
-        hk.plane = planeD;
-        gemm_layer<PREC, NT, NT, 0, EPI_CVT>(st, net, 0, A, none, B, heads, ring, g, hk);
+          gemm_layer<PREC, NT, NT, 0, EPI_CVT>(st, net, 0, A, none, B, heads, ring, g, hk);
       }
     }
     if constexpr (F16) {  // a scaled gradient left the fp16 range
@@ -540,12 +540,14 @@ __device__ __forceinline__ float frag_sum(const s16x8& f, float acc) {
 // side and the matrix side of the register-prefetch form of rounds 1-2 separately gave 2.66 ms and 1.97 ms of its
 // 3.08 ms), so the operands travel HBM -> LDS by LDS-DMA (`global_load_lds_dwordx4`), never through
 // registers: a ring of NSTAGE = 4 chunk slots keeps two to three chunks (64-96 KiB per CU) in flight.
-//   * A chunk slot holds the RAW packed pair-rows of the workgroup's rows of A and B, 64-row block by block and plane
-//     by plane: 2 KiB = two pieces of 16 pair-rows x 64 bytes, each ONE contiguous KiB of the chunk-major T-layout
-//     and one LDS-DMA instruction.  The LDS side of such an instruction is lane-linear by construction; the global side
-//     is free, so lane (r, kg, mm) = 32 r + 16 kg + mm fetches granule 2 kg + r of pair-row mm: a lane (kg, m) of a
-//     consumer then finds samples 8 kg .. 8 kg + 8 of pair-row m in piece m >> 4 at slots 16 kg + (m & 15) and 32 + that,
-//     and each of its two ds_read_b128 touches every bank quad once per 16-lane group (conflict-free).
+//   * A chunk slot holds the RAW packed pair-rows of the workgroup's rows of A and B, one section per 64-row block: 32
+//     pair-rows x 16 samples x parts = 2 KiB per part, contiguous in the T-layout, fetched as pieces of 1 KiB (one
+//     LDS-DMA instruction each).  The LDS side of such an instruction is lane-linear by construction; the global side is
+//     free, so the granules (16 bytes) of a piece are permuted on the way such that the consumers' ds_read_b128 touch
+//     every bank quad once per 16-lane group (conflict-free).  x3 modes: a piece = 8 pair-rows x 8 granules (samples
+//     2c, 2c+1 with both parts); consumer lane (kg, m) wants granules 4 kg .. 4 kg + 3 of pair-row m and finds granule
+//     4 kg + r of piece m >> 3 at slot 16 r + (m & 7) + 8 (kg ^ (m >> 4)).  Single-pass modes: a piece = 16 pair-rows x
+//     4 granules; granule 2 kg + r of piece m >> 4 at slot 32 r + 16 kg + (m & 15).
 //   * Both halves of every dword are used by the lane that reads it: MFMA tile 0 of a 64-row block takes its EVEN
 //     rows, tile 1 the ODD rows (A: the wave's two row tiles; B: tiles 2j and 2j+1 of the workgroup).  Eight v_perm
 //     unzip two granules into the two tiles' operands.  B tile g therefore holds rows 64 (g>>1) + 2 q + (g&1).
@@ -556,8 +558,14 @@ __device__ __forceinline__ float frag_sum(const s16x8& f, float acc) {
 // No fp32 -> 16-bit conversion happens here: the savers stored the parts.  Bias gradient = row sums of A (v_dot2c).
 template <bool TWO>
 __device__ __forceinline__ void wg_dma(uint32_t voff, const void* gbase, uint32_t m0v) {
-  // one or two 1-KiB pieces of a section (the immediate offset advances the global and the LDS address alike)
+  // one or two 1-KiB pieces of a section (the immediate offset advances the global and the LDS address alike).
+  // The scalar operands are wave-uniform by construction; readfirstlane pins them to SGPRs (an "s" INPUT operand may
+  // otherwise arrive in a VGPR when the compiler formed the value with vector instructions).
   uint32_t keep;
+  m0v = __builtin_amdgcn_readfirstlane(m0v);
+  const uint64_t gb = (uint64_t)gbase;
+  const uint64_t gs = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(gb >> 32)) << 32) |
+                      (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)gb);
   if (TWO)
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
@@ -567,7 +575,7 @@ __device__ __forceinline__ void wg_dma(uint32_t voff, const void* gbase, uint32_
         "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "v"(voff), "s"(m0v), "s"((uint64_t)gbase)
+        : "v"(voff), "s"(m0v), "s"(gs)
         : "memory");
   else
     asm volatile(
@@ -577,23 +585,23 @@ __device__ __forceinline__ void wg_dma(uint32_t voff, const void* gbase, uint32_
         "global_load_lds_dwordx4 %1, %3\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "v"(voff), "s"(m0v), "s"((uint64_t)gbase)
+        : "v"(voff), "s"(m0v), "s"(gs)
         : "memory");
 }
 
 template <int NW, int MG, int BT, int PREC>
 __global__ __launch_bounds__(64 * NW, 2) void k_wgrad(WgArgs a) {  // (2 waves per SIMD: <= 256 registers)
   constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
-  constexpr int NPL = X3 ? 2 : 1;  // planes: high parts (, low parts)
+  constexpr int NPL = X3 ? 2 : 1;  // parts per value: high (, low)
   constexpr int CG = NW / MG;
   constexpr int A_ROWS = 64 * MG;
   constexpr int NTB = CG * BT;          // 32-row MFMA tiles of B per workgroup
   constexpr int NBB = (NTB + 1) / 2;    // 64-row blocks of B
   constexpr int NBP = (BT + 1) / 2;     // blocks of B a wave reads
-  constexpr int NQ = (MG + NBB) * NPL;  // (block, plane) sections of a chunk slot, 2 KiB each
+  constexpr int NQ = (MG + NBB) * NPL;  // 2-KiB halves of the sections (64-row blocks) of a chunk slot
   constexpr int SLOT = NQ * 2048;
   constexpr int NSTAGE = 4;
-  constexpr int PAIRS = (NQ + NW - 1) / NW;  // sections a wave loads per chunk (two LDS-DMA instructions each)
+  constexpr int PAIRS = (NQ + NW - 1) / NW;  // halves a wave loads per chunk (two LDS-DMA instructions each)
   static_assert(NW == 8 && (BT == 1 || BT % 2 == 0) && PAIRS <= 3 && NSTAGE * SLOT <= 160 * 1024, "k_wgrad geometry");
   __shared__ __attribute__((aligned(1024))) char lds[NSTAGE * SLOT];
   const WgJob jb = a.job[blockIdx.y];
@@ -620,16 +628,23 @@ __global__ __launch_bounds__(64 * NW, 2) void k_wgrad(WgArgs a) {  // (2 waves p
       for (int r = 0; r < 16; ++r) acc[ti][bt][r] = 0.f;
   float bsum[2] = {0.f, 0.f};
 
-  // ---- loader side: this wave's sections q = wave + 8 j of every chunk
+  // ---- loader side: this wave's section halves q = wave + 8 j of every chunk
   const int nq = (MG + nbb) * NPL;
-  const bool half_last = (b_pairs & 31) != 0;  // the last block of B holds 16 pair-rows: one piece
-  int my_inst = 0;                             // LDS-DMA instructions of this wave per chunk (wave-uniform)
+  const bool half_last = (b_pairs & 31) != 0;  // the last block of B holds 16 pair-rows: half a section
+  auto pieces_of = [&](int q) {                // LDS-DMA instructions of half q (wave-uniform)
+    if (half_last && q / NPL == MG + nbb - 1) return X3 ? (q % NPL == 0 ? 2 : 0) : 1;
+    return 2;
+  };
+  int my_inst = 0;  // ... of this wave per chunk
 #pragma unroll
   for (int j = 0; j < PAIRS; ++j) {
     const int q = wave + NW * j;
-    if (q < nq) my_inst += (half_last && q / NPL == MG + nbb - 1) ? 1 : 2;
+    if (q < nq) my_inst += pieces_of(q);
   }
-  const uint32_t voff = (uint32_t)(((lane & 15) * 4 + ((lane >> 4) & 1) * 2 + (lane >> 5)) * 16);
+  // granule of the 1-KiB piece this lane fetches (it lands at LDS slot `lane` of the piece); x3: the second half of a
+  // section holds pieces 2, 3, whose slots swap the kg halves (voff ^ 64)
+  const uint32_t voff = X3 ? (uint32_t)(((lane & 7) * 8 + ((lane >> 3) & 1) * 4 + (lane >> 4)) * 16)
+                           : (uint32_t)(((lane & 15) * 4 + ((lane >> 4) & 1) * 2 + (lane >> 5)) * 16);
   auto issue = [&](int64_t cj) {
     const int64_t t = t0 + cj / (kTC / 16);
     const int64_t c16 = cj % (kTC / 16);
@@ -638,14 +653,16 @@ __global__ __launch_bounds__(64 * NW, 2) void k_wgrad(WgArgs a) {  // (2 waves p
     for (int j = 0; j < PAIRS; ++j) {
       const int q = wave + NW * j;
       if (q < nq) {
-        const int sec = q / NPL, pl = q % NPL;
+        const int sec = q / NPL, hf = q % NPL;
         const bool isA = sec < MG;
         const uint32_t* base = isA ? jb.A : jb.B;
         const int64_t pairs_tot = isA ? a_tot / 2 : b_pairs;
         const int64_t pair0 = isA ? rb * (A_ROWS / 2) + sec * 32 : (sec - MG) * 32;
-        const uint32_t* g = base + (t * 2 + pl) * pairs_tot * kTC + (c16 * pairs_tot + pair0) * kTRow;
-        if (half_last && sec == MG + nbb - 1) wg_dma<false>(voff, g, slot + (uint32_t)q * 2048u);
-        else wg_dma<true>(voff, g, slot + (uint32_t)q * 2048u);
+        const uint32_t* g = base + t * 2 * pairs_tot * kTC + (c16 * pairs_tot + pair0) * (kTRow * NPL) + hf * 512;
+        const uint32_t vo = voff ^ (uint32_t)(hf * 64);
+        const int np = pieces_of(q);
+        if (np == 2) wg_dma<true>(vo, g, slot + (uint32_t)q * 2048u);
+        else if (np == 1) wg_dma<false>(vo, g, slot + (uint32_t)q * 2048u);
       }
     }
   };
@@ -663,10 +680,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_wgrad(WgArgs a) {  // (2 waves p
     }
   };
 
-  const int lane_off = (m >> 4) * 1024 + (kg * 16 + (m & 15)) * 16;  // granules 2 kg, 2 kg + 1 (+512) of pair-row m
+  // this lane's first granule inside a section; the following ones RSTEP bytes apart
+  constexpr int NG = 2 * NPL, RSTEP = X3 ? 256 : 512;
+  const int lane_off = X3 ? (m >> 3) * 1024 + ((m & 7) + 8 * (kg ^ ((m >> 4) & 1))) * 16 : (m >> 4) * 1024 + (kg * 16 + (m & 15)) * 16;
   Frag af[2];    // current chunk: the wave's A rows, tile 0 (even rows) / tile 1 (odd rows)
   Frag bfr[BT];  // ... its B tiles
-  u32x4 rawA[NPL][2], rawB[NBP][NPL][2];
+  u32x4 rawA[NG], rawB[NBP][NG];  // samples 8 kg .. + 8 of the lane's pair-row: NG granules per section
   // One step = [wait + barrier: chunk ci+1 landed, slot of chunk ci free] [refill that slot] [raw reads of chunk ci+1]
   // [MFMAs of chunk ci] [unzip chunk ci+1].  ACT / BIAS (wave-uniform) are compile-time inside the loops so that the
   // steady-state step is ONE basic block after its scalar head: the scheduler is then told to place the ~4.5 VALU
@@ -676,16 +695,32 @@ __global__ __launch_bounds__(64 * NW, 2) void k_wgrad(WgArgs a) {  // (2 waves p
   auto reads = [&](int64_t cj, auto ACT) {
     const char* sl = lds + (int)(cj % NSTAGE) * SLOT + lane_off;
 #pragma unroll
-    for (int pl = 0; pl < NPL; ++pl)
+    for (int r = 0; r < NG; ++r) {
+      rawA[r] = *reinterpret_cast<const u32x4*>(sl + rg * (2048 * NPL) + r * RSTEP);
+      if constexpr (decltype(ACT)::value) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        rawA[pl][h] = *reinterpret_cast<const u32x4*>(sl + (rg * NPL + pl) * 2048 + h * 512);
-        if constexpr (decltype(ACT)::value) {
-#pragma unroll
-          for (int jj = 0; jj < NBP; ++jj)
-            rawB[jj][pl][h] = *reinterpret_cast<const u32x4*>(sl + ((MG + (g0 >> 1) + jj) * NPL + pl) * 2048 + h * 512);
-        }
+        for (int jj = 0; jj < NBP; ++jj)
+          rawB[jj][r] = *reinterpret_cast<const u32x4*>(sl + (MG + (g0 >> 1) + jj) * (2048 * NPL) + r * RSTEP);
       }
+    }
+  };
+  // the operands of the even-row and the odd-row tile out of a section's granules
+  auto unzip_section = [&](const u32x4 (&g)[NG], Frag& ev, Frag& od) {
+    if constexpr (X3) {  // granule r = samples 2r, 2r+1: (high, low, high, low) dwords
+      u32x4 eh, oh, el, ol;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        eh[r] = __builtin_amdgcn_perm(g[r][2], g[r][0], 0x05040100u);
+        oh[r] = __builtin_amdgcn_perm(g[r][2], g[r][0], 0x07060302u);
+        el[r] = __builtin_amdgcn_perm(g[r][3], g[r][1], 0x05040100u);
+        ol[r] = __builtin_amdgcn_perm(g[r][3], g[r][1], 0x07060302u);
+      }
+      ev.hi = __builtin_bit_cast(s16x8, eh); od.hi = __builtin_bit_cast(s16x8, oh);
+      ev.lo = __builtin_bit_cast(s16x8, unscale_lo<F16>(el)); od.lo = __builtin_bit_cast(s16x8, unscale_lo<F16>(ol));
+    } else {
+      unzip_rows(g[0], g[1], ev.hi, od.hi);
+      ev.lo = ev.hi; od.lo = od.hi;
+    }
   };
   auto mfmas = [&](auto ACT, auto BIAS) {
     if constexpr (decltype(BIAS)::value) {
@@ -711,22 +746,19 @@ __global__ __launch_bounds__(64 * NW, 2) void k_wgrad(WgArgs a) {  // (2 waves p
     }
   };
   auto unzip = [&](auto ACT) {
-    unzip_rows(rawA[0][0], rawA[0][1], af[0].hi, af[1].hi);
-    if (X3) unzip_rows(unscale_lo<F16>(rawA[NPL - 1][0]), unscale_lo<F16>(rawA[NPL - 1][1]), af[0].lo, af[1].lo);
+    unzip_section(rawA, af[0], af[1]);
     if constexpr (decltype(ACT)::value) {
 #pragma unroll
       for (int jj = 0; jj < NBP; ++jj) {
-        s16x8 ev, od, evl, odl;
-        unzip_rows(rawB[jj][0][0], rawB[jj][0][1], ev, od);
-        evl = ev; odl = od;
-        if (X3) unzip_rows(unscale_lo<F16>(rawB[jj][NPL - 1][0]), unscale_lo<F16>(rawB[jj][NPL - 1][1]), evl, odl);
+        Frag ev, od;
+        unzip_section(rawB[jj], ev, od);
         if constexpr (BT == 1) {  // one tile per wave: the even or the odd rows of the block it shares with its neighbour
           const bool odd = g0 & 1;
-          bfr[0].hi = odd ? od : ev;
-          bfr[0].lo = odd ? odl : evl;
+          bfr[0].hi = odd ? od.hi : ev.hi;
+          bfr[0].lo = odd ? od.lo : ev.lo;
         } else {
-          bfr[2 * jj].hi = ev; bfr[2 * jj].lo = evl;
-          bfr[2 * jj + 1].hi = od; bfr[2 * jj + 1].lo = odl;
+          bfr[2 * jj] = ev;
+          bfr[2 * jj + 1] = od;
         }
       }
     }
@@ -757,7 +789,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_wgrad(WgArgs a) {  // (2 waves p
       unzip(ACT);
       if constexpr (kAct) {
         constexpr int NM = 2 * BT * (X3 ? 3 : 1);
-        constexpr int NR = 2 * NPL * (1 + NBP);
+        constexpr int NR = NG * (1 + NBP);
 #pragma unroll
         for (int k = 0; k < NM; ++k) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // one MFMA
@@ -856,9 +888,9 @@ __global__ void k_wgrad_reduce(RdArgs a) {
 // ------------------------------------------------------------------ head weights
 // dW_sigma[f] = sum_s dsigma_s h_{L-1}[f,s];  dW_rgb[c,f] = sum_s dz_c,s Bo[f,s];  biases = sums of dsigma / dz.
 // Wave w owns 2 NT pair-rows of h_{L-1} and NT pair-rows of Bo (packed T-layout: value = high part + low part).
-// Four lanes per pair-row, four samples (one 16-byte granule) each: the wave's pair-rows of one 16-sample chunk are
-// one contiguous run of the chunk-major layout (1 KiB for 16 pair-rows); with fewer pair-rows per wave the lane groups
-// left over take the following chunks.
+// Four lanes per pair-row, four samples each: the wave's pair-rows of one 16-sample chunk are one contiguous run of the
+// T-layout (2 KiB for 16 pair-rows with both parts); with fewer pair-rows per wave the lane groups left over take the
+// following chunks.
 struct HeadsArgs {
   const uint32_t *H, *Bo;
   const float* dhead;
@@ -879,11 +911,18 @@ __global__ __launch_bounds__(kThreads) void k_heads_wgrad(HeadsArgs a) {
   const int s4 = (lane & 3) * 4, idx = lane >> 2;
   const int qh = idx % PH, ch = idx / PH, qb = idx % PB, cb = idx / PB;
   float accS[2] = {0.f, 0.f}, accR[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, accB[4] = {0.f, 0.f, 0.f, 0.f};
-  // the two rows of a pair-row at four samples: v[row parity][sample]
-  auto load_pair = [&](const uint32_t* p, int64_t plane, float (&v)[2][4]) {
-    const u32x4 h = *reinterpret_cast<const u32x4*>(p);
-    u32x4 l = {0u, 0u, 0u, 0u};
-    if (X3) l = *reinterpret_cast<const u32x4*>(p + plane);
+  // the two rows of a pair-row at four samples: v[row parity][sample]; p: first part of the first sample
+  constexpr int NPL = X3 ? 2 : 1;
+  auto load_pair = [&](const uint32_t* p, float (&v)[2][4]) {
+    uint32_t h[4], l[4] = {0u, 0u, 0u, 0u};
+    if constexpr (X3) {  // (high, low) side by side
+      const u32x4 w0 = *reinterpret_cast<const u32x4*>(p), w1 = *reinterpret_cast<const u32x4*>(p + 4);
+      h[0] = w0[0]; l[0] = w0[1]; h[1] = w0[2]; l[1] = w0[3];
+      h[2] = w1[0]; l[2] = w1[1]; h[3] = w1[2]; l[3] = w1[3];
+    } else {
+      const u32x4 w0 = *reinterpret_cast<const u32x4*>(p);
+      h[0] = w0[0]; h[1] = w0[1]; h[2] = w0[2]; h[3] = w0[3];
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       v[0][i] = from_h<F16>((short)(h[i] & 0xffffu));
@@ -904,25 +943,25 @@ __global__ __launch_bounds__(kThreads) void k_heads_wgrad(HeadsArgs a) {
         accB[c] += d2[0] + d2[1];
       }
     }
-    const uint32_t* hp = a.H + t * D * kTC + (PH * wave + qh) * kTRow + s4;
+    const uint32_t* hp = a.H + t * D * kTC + ((PH * wave + qh) * kTRow + s4) * NPL;
 #pragma unroll
     for (int c0 = 0; c0 < NCH; c0 += CH) {
       const int c = c0 + ch;
       const f32x4 ds = *reinterpret_cast<const f32x4*>(dht + 3 * kTC + 16 * c + s4);
       float h[2][4];
-      load_pair(hp + (int64_t)c * (D / 2) * kTRow, (D / 2) * kTC, h);
+      load_pair(hp + (int64_t)c * (D / 2) * kTRow * NPL, h);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         accS[0] += ds[i] * h[0][i];
         accS[1] += ds[i] * h[1][i];
       }
     }
-    const uint32_t* bp = a.Bo + t * (D / 2) * kTC + (PB * wave + qb) * kTRow + s4;
+    const uint32_t* bp = a.Bo + t * (D / 2) * kTC + ((PB * wave + qb) * kTRow + s4) * NPL;
 #pragma unroll
     for (int c0 = 0; c0 < NCH; c0 += CB) {
       const int c = c0 + cb;
       float b[2][4];
-      load_pair(bp + (int64_t)c * (D / 4) * kTRow, (D / 4) * kTC, b);
+      load_pair(bp + (int64_t)c * (D / 4) * kTRow * NPL, b);
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const f32x4 dz = *reinterpret_cast<const f32x4*>(dht + k * kTC + 16 * c + s4);
