@@ -190,6 +190,7 @@ def cpu_baseline_c1(dev=None, target_s=4.0):
 # ---------------------------------------------------------------- training workload (configs[3])
 T_H, T_W, T_FOCAL, T_RAYS = 378, 504, 407.6, 4096  # LLFF images_8 geometry
 FLOP_PER_RAY_TRAIN = S * FLOP_DENSITY + 3 * (S + NI) * FLOP_FULL  # density pass (no grad) + fwd + dgrad + wgrad
+TRAIN_BYTES_PER_SAMPLE = {True: 10.4e3 + 9.9e3 + 21.8e3, False: 5.2e3 + 5.1e3 + 10.9e3}  # fwd + bwd + wgrad/heads, x3 / single-pass
 
 
 def train_poses():
@@ -270,7 +271,12 @@ def train_main(args, rank, world, dev, dist, backend):
                        "rays_per_step": T_RAYS, "parallelism": f"dp{world} (ray-batch data parallel)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_TFLOPS, "traffic": None, "kernel": "whole step",
-                         "flop_per_ray": FLOP_PER_RAY_TRAIN},
+                         "flop_per_ray": FLOP_PER_RAY_TRAIN,
+                         # the step is co-limited by HBM: algorithmic bytes of the saved 16-bit parts
+                         # (forward writes, backward writes, weight-gradient reads), float32-sized in the x3 modes
+                         "hbm": {"bytes_per_step": TRAIN_BYTES_PER_SAMPLE[args.precision in ("fp16x3", "bf16x3")] * T_RAYS * (S + NI),
+                                 "achieved_tbps": TRAIN_BYTES_PER_SAMPLE[args.precision in ("fp16x3", "bf16x3")] * (S + NI) * value / world / 1e12,
+                                 "peak_tbps": 8.0}},
             "loss": float(loss),
         }
         print(json.dumps(line), flush=True)

@@ -11,3 +11,5 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpu
 bash $R/tools/run_pmc.sh r03occ --workload occgrid || exit $?
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r03train -- python3 $R/bench.py --workload train --steps 20 --warmup 3 > $R/gpurun_out/prof_r03train.log 2>&1 || exit $?
 echo profiles done
+bash $R/tools/run_pmc.sh r03train --workload train --steps 3 --warmup 1 || exit $?
+echo train pmc done
