@@ -80,7 +80,8 @@ SIGNATURES = {
     "fsn_nerf_train_workspace_floats": (_i64, [_PD, _i, _i64]),
     "fsn_nerf_train_fwd": (_i, [_PD, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "fsn_nerf_train_fwd_rays": (_i, [_PD, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
-    "fsn_nerf_train_bwd": (_i, [_PD, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fsn_nerf_train_bwd": (_i, [_PD, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "fsn_grad_scale": (_i, [_vp, _i64, _vp, _vp]),
     "fsn_occlusion_reg_bwd": (_i, [_vp, _i64, _vp, _i64, _f, _f, _i, _vp, _vp, _vp, _vp]),
     "fsn_occgrid_march": (_i, [_vp, _vp, _i64, _vp, _i, _i, _vp, _f, _f, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fsn_packed_visibility": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _f, _f, _vp, _vp]),

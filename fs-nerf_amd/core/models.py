@@ -78,6 +78,7 @@ class _NerfTrainFn(torch.autograd.Function):
                                            model._mask(model.dir_mask, dev), status=word)
         ctx.desc, ctx.prec, ctx.work, ctx.out, ctx.model, ctx.word = desc, prec, work, out, model, word
         ctx.weights = [w.detach() for w in weights]
+        ctx.params = params  # (the leaf Parameters themselves: backward may accumulate into their .grad buffers)
         return out if ray_form else out.reshape(*x.shape[:-1], 4)
 
     @staticmethod
@@ -85,8 +86,17 @@ class _NerfTrainFn(torch.autograd.Function):
         if ctx.work is None:
             raise RuntimeError("NeRF backward ran twice on one forward: the saved activations are released after the "
                                "first pass (retain_graph is not supported on this path)")
-        dW, db = ops.nerf_train_bwd(ctx.desc, ctx.prec, ctx.weights, ctx.work, ctx.out, d_out.contiguous(), status=ctx.word)
+        # Gradient buffers owned by a flat bucket (shard.FlatGrads marks its parameters): the kernels ADD into p.grad on
+        # the device - exactly what autograd's AccumulateGrad would do with returned tensors, minus 24 temporaries and 24
+        # add launches per step - and autograd is handed None for them.  Anything else gets the gradients returned.
+        n = len(ctx.params) // 2
+        sink = all(getattr(p, "_fsn_grad_sink", False) and p.requires_grad and p.grad is not None and p.grad.is_contiguous()
+                   and p.grad.dtype == torch.float32 and p.grad.device == d_out.device for p in ctx.params)
+        into = ([p.grad for p in ctx.params[:n]], [p.grad for p in ctx.params[n:]]) if sink else None
+        dW, db = ops.nerf_train_bwd(ctx.desc, ctx.prec, ctx.weights, ctx.work, ctx.out, d_out.contiguous(), status=ctx.word,
+                                    into=into)
         ctx.work = None
+        ctx.params = None
         # fp16 range guard without a per-step host sync.  When this call's launches reported values outside the fp16
         # range, the backward kernels have written ITS gradients as zeros on the device; the call's word is folded
         # (device ops) into the device's step flag, on which FusedAdam skips the whole update - a skipped step, like a
@@ -102,6 +112,8 @@ class _NerfTrainFn(torch.autograd.Function):
                 if bits:
                     model.fall_back("training steps (an overflowing step's gradients were zeroed on the device and its "
                                     "optimizer update skipped)", bits)
+        if sink:
+            return (None, None, None) + (None,) * (2 * n)
         db = [g.reshape(-1) for g in db]
         return (None, None, None, *dW, *db)
 

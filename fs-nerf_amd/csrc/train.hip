@@ -122,14 +122,55 @@ extern "C" int fsn_nerf_train_fwd_rays(const fsn_mlp_desc* desc, int prec, const
 
 extern "C" int fsn_nerf_train_bwd(const fsn_mlp_desc* desc, int prec, const float* const* W, int64_t n, float* ws,
                                   const float* out, const float* d_out, const float* grad_scale, float* const* dW,
-                                  float* const* db, uint32_t* status, fsn_stream_t stream) {
+                                  float* const* db, int accumulate, uint32_t* status, fsn_stream_t stream) {
   int rc = check_desc(desc);
   if (rc != FSN_OK) return rc;
   FSN_REQUIRE(prec >= 0 && prec <= FSN_PREC_FP16, FSN_E_INVALID, "fsn_nerf_train_bwd: unknown precision");
   FSN_REQUIRE(W && dW && db, FSN_E_INVALID, "fsn_nerf_train_bwd: null pointer");
   FSN_REQUIRE(n > 0 && ws && out && d_out, FSN_E_INVALID, "fsn_nerf_train_bwd: needs the forward's workspace (n > 0)");
   FSN_REQUIRE(n < (1ll << 31), FSN_E_UNSUPPORTED, "fsn_nerf_train_bwd: n too large for one call");
-  return fused_train_bwd(desc, prec, W, n, ws, out, d_out, grad_scale, dW, db, status, as_stream(stream));
+  return fused_train_bwd(desc, prec, W, n, ws, out, d_out, grad_scale, dW, db, accumulate != 0, status, as_stream(stream));
+}
+
+// max |d_out| as the bits of a non-negative float (unsigned order = float order; a NaN's bits lie above infinity's and
+// so survive the maximum), last workgroup forms the scale
+__global__ void k_grad_scale(const float* __restrict__ x, int64_t n, float* __restrict__ buf) {
+  uint32_t mx = 0u;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t b = __float_as_uint(x[i]) & 0x7fffffffu;
+    mx = b > mx ? b : mx;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)mx, m, 64);
+    mx = o > mx ? o : mx;
+  }
+  uint32_t* w = reinterpret_cast<uint32_t*>(buf);
+  __shared__ uint32_t last;
+  if ((threadIdx.x & 63) == 0) atomicMax(w + 1, mx);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    last = atomicAdd(w + 2, 1u) == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (last && threadIdx.x == 0) {
+    __threadfence();
+    const float amax = __uint_as_float(atomicMax(w + 1, 0u));
+    float e = 0.f;
+    const float q = 1024.0f / amax;  // inf for amax = 0 and for subnormal maxima, 0 for inf, NaN for NaN
+    if (q > 0.f && q < __builtin_inff()) e = fminf(fmaxf(floorf(log2f(q)), -40.0f), 60.0f);  // (else 0, as nan_to_num did)
+    buf[0] = ldexpf(1.0f, (int)e);
+  }
+}
+
+extern "C" int fsn_grad_scale(const float* d_out, int64_t n, float* buf, fsn_stream_t stream) {
+  FSN_REQUIRE(n >= 0 && buf && (n == 0 || d_out), FSN_E_INVALID, "fsn_grad_scale: bad arguments");
+  int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
+  blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
+  k_grad_scale<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(d_out, n, buf);
+  FSN_LAUNCH_CHECK("k_grad_scale");
+  return FSN_OK;
 }
 
 extern "C" int fsn_composite_packed_bwd(const float* sigmas, const float* rgbs, const float* t_starts, const float* t_ends,

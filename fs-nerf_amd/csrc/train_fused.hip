@@ -850,6 +850,7 @@ struct RdArgs {
   RdJob job[2 * kMaxLayers + 4];
   const float* scale;
   const uint32_t* status;  // fp16 modes: this call's range-guard word (null in the bf16 modes); bit 0 -> zero gradients
+  int32_t accumulate;      // add to dW / db instead of overwriting them
 };
 
 __global__ void k_wgrad_reduce(RdArgs a) {
@@ -875,13 +876,16 @@ __global__ void k_wgrad_reduce(RdArgs a) {
     if (colo >= 0) {
       float sum = 0.f;
       for (int p = 0; p < jb.nsplit; ++p) sum += jb.part[(int64_t)p * tot + e];
-      jb.dW[(int64_t)row * jb.ld + colo] = skip ? 0.f : sum * inv;
+      float* dst = jb.dW + (int64_t)row * jb.ld + colo;
+      const float v = skip ? 0.f : sum * inv;
+      *dst = a.accumulate ? *dst + v : v;
     }
   }
   if (jb.bpart && e < jb.a_rows) {
     float sum = 0.f;
     for (int p = 0; p < jb.nsplit; ++p) sum += jb.bpart[(int64_t)p * jb.a_rows + e];
-    jb.db[e] = skip ? 0.f : sum * inv;
+    const float v = skip ? 0.f : sum * inv;
+    jb.db[e] = a.accumulate ? jb.db[e] + v : v;
   }
 }
 
@@ -1010,6 +1014,7 @@ struct HeadsRdArgs {
   const float* scale;
   float *dWs, *dbs, *dWr, *dbr;
   const uint32_t* status;  // as in RdArgs
+  int32_t accumulate;
 };
 __global__ void k_heads_reduce(HeadsRdArgs a) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1020,10 +1025,12 @@ __global__ void k_heads_reduce(HeadsRdArgs a) {
   for (int p = 0; p < a.nsplit; ++p) sum += a.hpart[(int64_t)p * n + e];
   sum *= inv;
   if (a.status && (a.status[0] & 1u)) sum = 0.f;
-  if (e < a.D) a.dWs[e] = sum;
-  else if (e < a.D + 3 * (a.D / 2)) a.dWr[e - a.D] = sum;
-  else if (e < n - 1) a.dbr[e - a.D - 3 * (a.D / 2)] = sum;
-  else a.dbs[0] = sum;
+  float* dst;
+  if (e < a.D) dst = a.dWs + e;
+  else if (e < a.D + 3 * (a.D / 2)) dst = a.dWr + (e - a.D);
+  else if (e < n - 1) dst = a.dbr + (e - a.D - 3 * (a.D / 2));
+  else dst = a.dbs;
+  *dst = a.accumulate ? *dst + sum : sum;
 }
 
 // ------------------------------------------------------------------ host side
@@ -1108,7 +1115,7 @@ int fused_train_fwd(const fsn_mlp_desc* d, int prec, const float* const* W, cons
 
 int fused_train_bwd(const fsn_mlp_desc* d, int prec, const float* const* W, int64_t n, float* ws, const float* out,
                     const float* d_out, const float* grad_scale_dev, float* const* dW, float* const* db,
-                    uint32_t* status, hipStream_t s) {
+                    bool accumulate, uint32_t* status, hipStream_t s) {
   FusedLayout F;
   const char* why;
   int rc = make_fused_layout(*d, prec, n, F, &why);
@@ -1204,6 +1211,7 @@ int fused_train_bwd(const fsn_mlp_desc* d, int prec, const float* const* W, int6
   }
   rd.scale = grad_scale_dev;
   rd.status = prec_is_f16(prec) ? status : nullptr;  // (only the fp16 modes can overflow)
+  rd.accumulate = accumulate ? 1 : 0;
   {
     dim3 grid((unsigned)((D * D + 255) / 256), (unsigned)nrd);
     k_wgrad_reduce<<<grid, 256, 0, s>>>(rd);
@@ -1225,7 +1233,7 @@ int fused_train_bwd(const fsn_mlp_desc* d, int prec, const float* const* W, int6
     }
     FSN_LAUNCH_CHECK("k_heads_wgrad");
     HeadsRdArgs hr{ws + F.hpart, F.nsplit_heads, D, grad_scale_dev, dW[L], db[L], dW[L + 3], db[L + 3],
-                   prec_is_f16(prec) ? status : nullptr};
+                   prec_is_f16(prec) ? status : nullptr, accumulate ? 1 : 0};
     const int nn = D + 3 * (D / 2) + 4;
     k_heads_reduce<<<(unsigned)((nn + 255) / 256), 256, 0, s>>>(hr);
     FSN_LAUNCH_CHECK("k_heads_reduce");

@@ -621,27 +621,43 @@ def nerf_train_fwd(desc: L.MlpDesc, prec: int, weights: Sequence[Tensor], biases
 
 def grad_scale_for(d_out: Tensor) -> Tensor:
     """Power of two that brings max|d_out| to ~2^10 (device scalar, no host sync): the fp16 MFMA modes of the
-    backward multiply d_out by it on entry and divide the gradients by it at the end."""
-    amax = d_out.detach().abs().amax().to(torch.float32)
-    e = torch.floor(torch.log2(1024.0 / amax))
-    e = torch.nan_to_num(e, nan=0.0, posinf=0.0, neginf=0.0).clamp(-40.0, 60.0)
-    return torch.exp2(e).reshape(1)
+    backward multiply d_out by it on entry and divide the gradients by it at the end.  One launch (fsn_grad_scale):
+    2^clamp(floor(log2(1024 / max|d_out|)), -40, 60), 1 when the maximum is 0 / inf / NaN."""
+    d = _f32(d_out.detach(), "d_out").reshape(-1)
+    buf = torch.zeros(4, dtype=torch.float32, device=d.device)
+    with torch.cuda.device(d.device):
+        L.check(L.lib().fsn_grad_scale(_p(d), d.numel(), _p(buf), _stream()), "fsn_grad_scale")
+    return buf[:1]
 
 
 def nerf_train_bwd(desc: L.MlpDesc, prec: int, weights: Sequence[Tensor], work: Tensor, out: Tensor, d_out: Tensor,
-                   status: Optional[Tensor] = None):
-    """-> (d_weights, d_biases) lists in state_dict order.  `status`: the word given to nerf_train_fwd."""
+                   status: Optional[Tensor] = None, into: Optional[Tuple[Sequence[Tensor], Sequence[Tensor]]] = None):
+    """-> (d_weights, d_biases) lists in state_dict order.  `status`: the word given to nerf_train_fwd.
+    `into` = (weight .grad buffers, bias .grad buffers): the gradients are ADDED to them on the device (what autograd's
+    AccumulateGrad does with returned tensors, without the temporaries and one add launch per parameter); -> into."""
     ws_ = [_f32(w.detach(), "weight") for w in weights]
     d_out = _f32(d_out, "d_out").reshape(-1, 4)
     n = d_out.shape[0]
-    if n == 0:  # e.g. the all-background first batch of an empty occupancy grid (run-nerf.py:243 precedes :293)
-        return [torch.zeros_like(w) for w in ws_], [torch.zeros(w.shape[0], device=w.device) for w in ws_]
-    dW = [torch.empty_like(w) for w in ws_]
-    db = [torch.empty(w.shape[0], device=w.device, dtype=torch.float32) for w in ws_]
+    if into is not None:
+        for g in list(into[0]) + list(into[1]):
+            if not (g.is_cuda and g.dtype == torch.float32 and g.is_contiguous()):
+                raise ValueError("nerf_train_bwd: `into` buffers must be contiguous float32 GPU tensors (they are written in place)")
+        dW, db = list(into[0]), [g.view(-1) for g in into[1]]
+        if len(dW) != len(ws_) or len(db) != len(ws_) or any(g.shape != w.shape for g, w in zip(dW, ws_)) or \
+                any(g.numel() != w.shape[0] for g, w in zip(db, ws_)):
+            raise ValueError("nerf_train_bwd: `into` must hold one gradient buffer per weight / bias, of its shape")
+        if n == 0:
+            return dW, db
+    else:
+        if n == 0:  # e.g. the all-background first batch of an empty occupancy grid (run-nerf.py:243 precedes :293)
+            return [torch.zeros_like(w) for w in ws_], [torch.zeros(w.shape[0], device=w.device) for w in ws_]
+        dW = [torch.empty_like(w) for w in ws_]
+        db = [torch.empty(w.shape[0], device=w.device, dtype=torch.float32) for w in ws_]
     scale = grad_scale_for(d_out) if prec in (L.FSN_PREC_FP16X3, L.FSN_PREC_FP16) else None
     with torch.cuda.device(work.device):
         L.check(L.lib().fsn_nerf_train_bwd(C.byref(desc), prec, _ptr_array(ws_), n, _p(work), _p(out), _p(d_out),
-                                           _p(scale), _ptr_array(dW), _ptr_array(db), _p(status), _stream()),
+                                           _p(scale), _ptr_array(dW), _ptr_array(db), 0 if into is None else 1,
+                                           _p(status), _stream()),
                 "fsn_nerf_train_bwd")
     return dW, db
 

@@ -98,6 +98,7 @@ class FlatGrads:
             elif g.data_ptr() != v.data_ptr() or g.stride() != v.stride():
                 v.copy_(g)
             p.grad = v
+            p._fsn_grad_sink = True  # core/models.py: the backward kernels may accumulate into this buffer directly
 
     def zero(self) -> None:
         """`optimizer.zero_grad(set_to_none=False)` for the whole model in one fill."""

@@ -289,9 +289,17 @@ int fsn_nerf_train_fwd_rays(const fsn_mlp_desc* desc, int prec, const float* con
                             const float* rays_o, const float* rays_d, const int64_t* ray_indices, const float* t_starts,
                             const float* t_ends, const float* pos_mask, const float* dir_mask, int64_t n,
                             float* workspace, float* out, uint32_t* status, fsn_stream_t stream);
+/* accumulate != 0: the gradients are ADDED to d_weights / d_biases (the caller's .grad buffers: what autograd's
+ * AccumulateGrad would do with a returned tensor, without the temporaries and the 24 add launches per step);
+ * 0: they are overwritten.  A flagged call (bit 0 of *status) contributes zeros either way. */
 int fsn_nerf_train_bwd(const fsn_mlp_desc* desc, int prec, const float* const* weights, int64_t n, float* workspace,
                        const float* out, const float* d_out, const float* grad_scale, float* const* d_weights,
-                       float* const* d_biases, uint32_t* status, fsn_stream_t stream);
+                       float* const* d_biases, int accumulate, uint32_t* status, fsn_stream_t stream);
+/* The power-of-two `grad_scale` of the fp16 modes' backward in one launch: 2^floor(log2(1024 / max|d_out|)), exponent
+ * clamped to [-40, 60], 1 when the maximum is 0 / inf / NaN (the arithmetic of ops.grad_scale_for, which took nine
+ * elementwise / reduction launches).  buf: 4 device floats, ZEROED by the caller; buf[0] receives the scale (buf[1..2]
+ * are the launch's reduction words). */
+int fsn_grad_scale(const float* d_out, int64_t n, float* buf, fsn_stream_t stream);
 /* backward of fsn_composite_packed_fwd with respect to sigmas and rgbs, given dL/dcolors [R,3] and
  * (optional) dL/dopacity [R]; dL/ddepth is not propagated. */
 int fsn_composite_packed_bwd(const float* sigmas, const float* rgbs, const float* t_starts, const float* t_ends,

@@ -175,3 +175,69 @@ def test_fused_adam_skips_a_flagged_step_and_checkpoints_its_state():
     one_step(opt2, net2)
     for p, w in zip(net2.parameters(), want):
         assert torch.equal(p.detach(), w), "resumed optimizer continues bit for bit"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp16x3", "bf16x3"])
+def test_backward_accumulates_into_the_flat_bucket_like_autograd(precision):
+    """Parameters whose .grad lives in a FlatGrads bucket: the backward kernels ADD into the buffers (no returned
+    temporaries, no add launch per parameter).  Same gradients as the returning path, and a second backward without
+    zero_grad accumulates exactly like AccumulateGrad does (g1 + g2 in fp32)."""
+    from fs_nerf_amd.core.optim import FusedAdam
+    dev = torch.device("cuda:0")
+    a, b = _model(dev).train(), _model(dev).train()
+    a.precision = b.precision = precision
+    opt = FusedAdam(a.parameters(), lr=1e-3)  # a: gradients in the bucket; b: plain autograd
+    assert all(getattr(p, "_fsn_grad_sink", False) for p in a.parameters())
+    gen = torch.Generator(device=dev).manual_seed(5)
+    x1, x2 = (torch.rand(777, 3, device=dev, generator=gen) * 2 - 1 for _ in range(2))
+    d1, d2 = (torch.nn.functional.normalize(torch.randn(777, 3, device=dev, generator=gen), dim=-1) for _ in range(2))
+    opt.zero_grad()
+    a(x1, d1).square().mean().backward()
+    b(x1, d1).square().mean().backward()
+    ptrs = [p.grad.data_ptr() for p in a.parameters()]
+    assert ptrs == [opt.grads.view(i).data_ptr() for i in range(len(ptrs))], "the gradients stayed views of the bucket"
+    g1 = [p.grad.clone() for p in b.parameters()]
+    for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
+        assert torch.equal(pa.grad, pb.grad), (n, float((pa.grad - pb.grad).abs().max()))
+    # second backward, no zero_grad: both paths accumulate
+    (3.0 * a(x2, d2).square().mean()).backward()
+    for p in b.parameters():
+        p.grad = None
+    (3.0 * b(x2, d2).square().mean()).backward()
+    for (n, pa), pb, g in zip(a.named_parameters(), b.parameters(), g1):
+        assert torch.equal(pa.grad, g + pb.grad), (n, float((pa.grad - (g + pb.grad)).abs().max()))
+    # a frozen parameter (no bucket view): the returning path takes over, nothing is written behind autograd's back
+    c = _model(dev).train()
+    c.precision = precision
+    FusedAdam(c.parameters(), lr=1e-3).zero_grad()
+    c.rgb.bias.requires_grad_(False)
+    c(x1, d1).square().mean().backward()
+    for (n, pc), g in zip(c.named_parameters(), g1):
+        if pc.requires_grad:
+            assert torch.equal(pc.grad, g), n
+
+
+@pytest.mark.gpu
+def test_grad_scale_is_one_launch_of_the_elementwise_chain():
+    from fs_nerf_amd import ops
+    dev = torch.device("cuda:0")
+
+    def chain(d_out):  # what nine elementwise / reduction launches computed before
+        amax = d_out.detach().abs().amax().to(torch.float32)
+        e = torch.floor(torch.log2(1024.0 / amax))
+        e = torch.nan_to_num(e, nan=0.0, posinf=0.0, neginf=0.0).clamp(-40.0, 60.0)
+        return torch.exp2(e).reshape(1)
+
+    gen = torch.Generator(device=dev).manual_seed(2)
+    for n in (1, 63, 4096 * 192 * 4 + 3):
+        for s in (1.0, 3e-9, 7e-31, 1e-44, 5e4, 3e17, 3e38):
+            d = torch.randn(n, device=dev, generator=gen) * s
+            got, want = ops.grad_scale_for(d), chain(d)
+            assert got.shape == (1,) and float(got) == float(want), (n, s, float(got), float(want))
+    for special in (0.0, float("inf"), float("nan"), -float("inf")):
+        d = torch.randn(1000, device=dev, generator=gen)
+        d[517] = special
+        if special == 0.0:
+            d.zero_()
+        assert float(ops.grad_scale_for(d)) == 1.0 == float(chain(d))
