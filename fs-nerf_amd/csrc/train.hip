@@ -136,7 +136,18 @@ extern "C" int fsn_nerf_train_bwd(const fsn_mlp_desc* desc, int prec, const floa
 // so survive the maximum), last workgroup forms the scale
 __global__ void k_grad_scale(const float* __restrict__ x, int64_t n, float* __restrict__ buf) {
   uint32_t mx = 0u;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n4 = ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) ? n / 4 : 0;  // 16-byte loads over the aligned bulk
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+  for (int64_t i = tid; i < n4; i += nthr) {
+    const u32x4 v = reinterpret_cast<const u32x4*>(x)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t b = v[k] & 0x7fffffffu;
+      mx = b > mx ? b : mx;
+    }
+  }
+  for (int64_t i = 4 * n4 + tid; i < n; i += nthr) {
     const uint32_t b = __float_as_uint(x[i]) & 0x7fffffffu;
     mx = b > mx ? b : mx;
   }
@@ -167,7 +178,7 @@ __global__ void k_grad_scale(const float* __restrict__ x, int64_t n, float* __re
 extern "C" int fsn_grad_scale(const float* d_out, int64_t n, float* buf, fsn_stream_t stream) {
   FSN_REQUIRE(n >= 0 && buf && (n == 0 || d_out), FSN_E_INVALID, "fsn_grad_scale: bad arguments");
   int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
-  blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
+  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
   k_grad_scale<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(d_out, n, buf);
   FSN_LAUNCH_CHECK("k_grad_scale");
   return FSN_OK;
