@@ -381,6 +381,106 @@ def occ_main(args, rank, world, dev, dist, backend):
         print(json.dumps(line), flush=True)
 
 
+def train_occ_main(args, rank, world, dev, dist, backend):
+    """`--workload train-occ`: the body of the reference's training loop as it stands (run-nerf.py:243-295): render_rays
+    with the OCCUPANCY estimator in the slot, train=True (march -> density pass under no_grad -> visibility cull ->
+    model(x, d) with gradients -> packed integration), MSE, backward, Adam, estimator.update_every_n_steps(step,
+    occ_eval_fn = model(x) * step_size).  4096 random rays per step out of eight 800x800 orbit views, render_step_size
+    5e-3, one 8x256 network.  For a DEFINED workload the grid the rays are sampled from is held fixed (the half-full
+    sphere grid of `--workload occgrid`) and the medium is thin (sigma ~ 3: the visibility cull keeps most marched
+    samples); the every-16th-step grid update is executed on a second estimator of the same size so that its cost is in the
+    timed region.  Unfused: several launches and one host sync (the data-dependent sample count) per step."""
+    from fs_nerf_amd import ops
+    from fs_nerf_amd.core.optim import FusedAdam
+    from fs_nerf_amd.render import rendering as Rm
+    from fs_nerf_amd.render.occgrid import OccGridEstimator
+    from fs_nerf_amd.utils import utilities as U
+    model = init_sd(42)
+    model.precision = args.precision
+    model.to(dev).train()
+    box = torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5])
+    est = OccGridEstimator(roi_aabb=box, resolution=OCC_RES, levels=1).to(dev)
+    ax = (torch.arange(OCC_RES) + 0.5) / OCC_RES * 3.0 - 1.5
+    x, y, z = torch.meshgrid(ax, ax, ax, indexing="ij")
+    est.set_binaries(((x * x + y * y + z * z).sqrt() < OCC_RADIUS)[None])
+    est.train()
+    est.generator = torch.Generator(device=dev).manual_seed(1000 + rank)
+    shadow = OccGridEstimator(roi_aabb=box, resolution=OCC_RES, levels=1).to(dev).train()
+    shadow.generator = torch.Generator(device=dev).manual_seed(3000 + rank)
+    opt = FusedAdam(model.parameters(), lr=5e-4)
+    rays = [U.get_rays(orbit_pose(45.0 * k), (H, W, FOCAL), dev) for k in range(8)]
+    ro = torch.cat([o.reshape(-1, 3) for o, _ in rays])
+    rd = torch.cat([d.reshape(-1, 3) for _, d in rays])
+    gt = torch.rand(ro.shape[0], 3, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
+    gen = torch.Generator(device=dev).manual_seed(2000 + rank)
+    kept = []
+
+    def occ_eval_fn(xx):
+        return model(xx) * OCC_STEP  # (run-nerf.py:288-289)
+
+    def step(i):
+        idx = torch.randint(0, ro.shape[0], (T_RAYS,), device=dev, generator=gen)
+        opt.zero_grad()
+        (rgb, _, _, _), ri, _ = Rm.render_rays(ro[idx], rd[idx], est, model, train=True, white_bkgd=True,
+                                               render_step_size=OCC_STEP, device=dev)
+        loss = torch.nn.functional.mse_loss(rgb, gt[idx])
+        loss.backward()
+        opt.grads.allreduce(average=False)
+        opt.step(grad_div=float(world))
+        with torch.no_grad():
+            shadow.update_every_n_steps(step=256 + i, occ_eval_fn=occ_eval_fn, occ_thre=1e-2)  # past the warm-up
+        kept.append(ri.numel())
+        return loss.detach()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    del kept[:]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    assert bool(torch.isfinite(loss))
+    if world > 1:
+        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        value = world * args.steps * T_RAYS / dt
+        n_kept = sum(kept) / max(len(kept), 1) / T_RAYS
+        with torch.no_grad():  # marched samples per ray on a batch drawn like the timed ones
+            est.eval()
+            idx = torch.randint(0, ro.shape[0], (T_RAYS,), device=dev, generator=gen)
+            _, _, _, cnt = ops.render_occ_fused(model.packed(), ro[idx].contiguous(), rd[idx].contiguous(), aabb=est.aabb,
+                                                res=est.resolution, levels=1, bits=est.bits, near_plane=0.0, far_plane=1e10,
+                                                step=OCC_STEP, max_steps=est.max_steps(OCC_STEP), bkgd=(1.0, 1.0, 1.0),
+                                                want_counts=True)
+        n_cand = float(cnt["n_cand"].float().mean())
+        flop_per_ray = n_cand * FLOP_DENSITY + 3 * n_kept * FLOP_FULL  # density pass + fwd + dgrad + wgrad on the kept samples
+        achieved = flop_per_ray * value / world / 1e12
+        line = {
+            "metric": "trained rays/sec (occupancy-grid estimator, render_step_size 5e-3, 8x256 MLP, fwd+bwd+Adam+grid update)",
+            "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "run-nerf.py:243-295 as it stands: 4096 random rays of eight 800x800 orbit views, occupancy "
+                                   "estimator (128^3 cells, sphere of radius 1.477 occupied, held fixed), render_step_size 5e-3, "
+                                   "one 8x256 NeRF (seed 42), MSE + fused Adam, update_every_n_steps on a second estimator",
+                       "rays_per_step": T_RAYS, "marched_samples_per_ray": n_cand, "kept_samples_per_ray": n_kept,
+                       "parallelism": f"dp{world} (ray-batch data parallel)"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_TFLOPS, "traffic": None, "kernel": "whole step", "flop_per_ray": flop_per_ray},
+            "loss": float(loss),
+        }
+        print(json.dumps(line), flush=True)
+
+
 # ---------------------------------------------------------------- N>1 self-launcher
 def _free_port():
     import socket
@@ -504,7 +604,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", choices=("render", "train", "occgrid"), default="render")
+    ap.add_argument("--workload", choices=("render", "train", "occgrid", "train-occ"), default="render")
     ap.add_argument("--precision", default=os.environ.get("FSN_BENCH_PREC", "fp16x3"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
@@ -515,9 +615,9 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="launcher self-test on the CPU (gloo); not a measurement")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 20 if args.workload == "train" else 3
+        args.steps = 20 if args.workload.startswith("train") else 3
     if args.warmup is None:
-        args.warmup = 3 if args.workload == "train" else 1
+        args.warmup = 3 if args.workload.startswith("train") else 1
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -543,8 +643,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    if args.workload in ("train", "occgrid"):
-        (train_main if args.workload == "train" else occ_main)(args, rank, world, dev, dist, backend)
+    if args.workload in ("train", "occgrid", "train-occ"):
+        {"train": train_main, "occgrid": occ_main, "train-occ": train_occ_main}[args.workload](args, rank, world, dev, dist, backend)
         if world > 1:
             dist.destroy_process_group()
         return
