@@ -451,7 +451,7 @@ def render_fused(pm_coarse: Optional[PackedMLP], pm_fine: PackedMLP, rays_o: Opt
 def sample_fused(pm_coarse: PackedMLP, rays_o: Tensor, rays_d: Tensor, *, near: float, far: float, n_samples: int,
                  n_importance: int, u: Optional[Tensor] = None, u_fine: Optional[Tensor] = None,
                  pos_mask: Optional[Tensor] = None, dir_mask: Optional[Tensor] = None,
-                 want_weights: bool = False):
+                 want_weights: bool = False, status: Optional[Tensor] = None):
     """The hierarchical sampler as ONE launch (fsn_render_rays_fused with two_phase = 2): stratified edges -> density
     pass of `pm_coarse` -> weights -> inverse-CDF resampling -> sorted union.  -> edges [R, S+NI+1] (and the coarse
     weights [R,S] when asked for): what StratifiedEstimator.sampling builds from five launches around a sigma_fn."""
@@ -481,7 +481,7 @@ def sample_fused(pm_coarse: PackedMLP, rays_o: Tensor, rays_d: Tensor, *, near: 
     if wc is not None:
         a.weights_coarse = wc.data_ptr()
     a.two_phase = 2
-    a.status = status_word(dev).data_ptr()
+    a.status = (status_word(dev) if status is None else status).data_ptr()  # `status`: a per-call word (training steps)
     if R > 0:
         with torch.cuda.device(dev):
             L.check(L.lib().fsn_render_rays_fused(C.byref(pm_coarse.desc), pm_coarse.prec, _p(pm_coarse.blob), None,

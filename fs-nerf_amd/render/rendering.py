@@ -264,12 +264,23 @@ def render_rays(rays_o: Tensor, rays_d: Tensor, estimator, model: nn.Module, tra
             near_, far_ = estimator.bounds(0.0, 1e10)
             kw_s = dict(near=near_, far=far_, n_samples=estimator.n_samples, n_importance=estimator.n_importance, u=uu,
                         u_fine=uf, pos_mask=model._mask(model.pos_mask, dev_), dir_mask=model._mask(model.dir_mask, dev_))
+            f16 = model.fp16_family(model.PRECISIONS[model.precision])
             with torch.no_grad():
-                edges = ops.sample_fused(model.packed(), rays_o, rays_d, **kw_s)
-                bits = ops.range_flags(dev_) if model.range_check is True and model.fp16_family(model.PRECISIONS[model.precision]) else 0
-                if bits:
-                    model.fall_back("the sampler's density pass", bits)
+                if needs_grad and f16 and model.range_check:
+                    # training step: no host read-back between the sampler and the forward (it cost the step 0.2 ms of idle
+                    # GPU).  The sampler reports into a word of its own, which joins the step's guard on the device like
+                    # the forward / backward pair's does (core/models.py:_NerfTrainFn): an overflowing density pass makes
+                    # this a skipped step (FusedAdam) and the host switches to bf16x3 at its next periodic look.
+                    word = torch.zeros(1, dtype=torch.int32, device=dev_)
+                    edges = ops.sample_fused(model.packed(), rays_o, rays_d, status=word, **kw_s)
+                    ops.step_flag(dev_).bitwise_or_(word)
+                    model._train_status(dev_).bitwise_or_(word)
+                else:
                     edges = ops.sample_fused(model.packed(), rays_o, rays_d, **kw_s)
+                    bits = ops.range_flags(dev_) if model.range_check is True and f16 else 0
+                    if bits:
+                        model.fall_back("the sampler's density pass", bits)
+                        edges = ops.sample_fused(model.packed(), rays_o, rays_d, **kw_s)
                 ray_indices, t_starts, t_ends = ops.edges_to_packed(edges)
         else:
             ray_indices, t_starts, t_ends = estimator.sampling(

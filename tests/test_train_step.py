@@ -674,3 +674,44 @@ def test_training_range_guard_is_per_call_not_a_shared_sticky_word():
     (good(x, d) * c).sum().backward()
     opt.step()
     assert any(not torch.equal(p.detach(), b) for p, b in zip(good.parameters(), before)), "clean step updates"
+
+
+@pytest.mark.gpu
+def test_training_sampler_overflow_joins_the_step_guard_without_a_host_read():
+    """render_rays(train=True) with the hierarchical sampler: the sampler's density pass reports into a per-call word that
+    is OR-ed into the step's guard on the device (no read-back between sampler and forward).  An overflowing pass makes
+    the step a skipped one; the host switches the model to bf16x3 at its next periodic look."""
+    from fs_nerf_amd import ops
+    from fs_nerf_amd.core.optim import FusedAdam
+    from fs_nerf_amd.render import rendering as Rm
+    dev = torch.device("cuda:0")
+    mk, sd_bad, _ = _guard_nets(dev)
+    m = mk(sd_bad, "fp16x3")
+    m.range_check_every = 2
+    opt = FusedAdam(m.parameters(), lr=1e-3)
+    est = Rm.StratifiedEstimator(2.0, 6.0, 16, 16).train()
+    est.generator = torch.Generator(device=dev).manual_seed(3)
+    gen = torch.Generator().manual_seed(5)
+    o = torch.tensor([0.0, 0.0, 4.0]).repeat(200, 1).to(dev)
+    d = torch.nn.functional.normalize(torch.randn(200, 3, generator=gen) * 0.2 + torch.tensor([0.0, 0.0, -1.0]), dim=-1).to(dev)
+    assert ops.range_ok(dev)
+    ops.step_flag(dev).zero_()
+
+    def step():
+        opt.zero_grad()
+        (rgb, _, _, _), _, _ = Rm.render_rays(o, d, est, m, train=True, white_bkgd=True, device=dev)
+        rgb.nan_to_num(0.0, 0.0, 0.0).square().mean().backward()
+
+    before = [p.detach().clone() for p in m.parameters()]
+    step()  # flagged on the device (sampler and forward both), not yet seen by the host
+    assert m.precision == "fp16x3" and int(ops.step_flag(dev).item()) & 1
+    assert ops.range_ok(dev), "the training step does not touch the inference path's sticky word"
+    opt.step()
+    assert all(torch.equal(p.detach(), b) for p, b in zip(m.parameters(), before)), "a flagged step is skipped"
+    with pytest.warns(RuntimeWarning, match="fp16 range"):
+        step()
+    assert m.precision == "bf16x3"
+    opt.step()
+    step()  # bf16x3: finite gradients, an update
+    assert all(bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+    assert int(ops.step_flag(dev).item()) == 0
