@@ -316,9 +316,15 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
 template <int NT, int PREC>
 static int launch_render(RenderKArgs k, int cus, hipStream_t s) {
   // rays per workgroup group: as many as fill one tile of the coarse pass, within the LDS arrays
-  constexpr int NG = groups_per_wave<NT, PREC>(), TILE = 128 * NG, CAP = NG == 1 ? 384 : kMaxGroupSamples;
+  // Rays per workgroup group: the per-ray stages (weights, resampling, integration) run one wave per ray, so a group of
+  // two rays (one 128-sample tile of a 64-sample coarse pass) leaves six waves idle in them; the x3 modes take two
+  // tiles' worth (four rays at 64+128: 424.3 -> 421.7 ms per frame), the two-group single-pass modes already do.
+#ifndef FSN_RENDER_G1
+#define FSN_RENDER_G1 2
+#endif
+  constexpr int NG = groups_per_wave<NT, PREC>(), TILE = 128 * NG, CAP = NG == 1 ? 384 * FSN_RENDER_G1 : kMaxGroupSamples;
   const int So = k.a.S + k.a.n_imp;
-  int g = TILE / k.a.S;
+  int g = (NG == 1 ? FSN_RENDER_G1 : 1) * TILE / k.a.S;
   if (g < 1) g = 1;
   if (g > CAP / So) g = CAP / So;
   if (g > kMaxG) g = kMaxG;
