@@ -26,9 +26,16 @@
 
 namespace fsn {
 
-constexpr int kMaxGroupSamples = 768;  // G * (S + n_imp) <= this (384 with one sample group per wave)
-constexpr int kMaxRaySamples = 384;    // S + n_imp <= this
+#ifdef FSN_RENDER_BIG  // experiment: groups of up to 8 rays (158.8 KB of LDS)
+constexpr int kMaxGroupSamples = 1536;  // G * (S + n_imp) <= this
+constexpr int kMaxGroupCoarse = 768;    // G * S <= this
+constexpr int kMaxG = 8;
+#else
+constexpr int kMaxGroupSamples = 768;  // G * (S + n_imp) <= this
+constexpr int kMaxGroupCoarse = 768;   // G * S <= this
 constexpr int kMaxG = 4;
+#endif
+constexpr int kMaxRaySamples = 384;    // S + n_imp <= this
 // sample groups of 16 per wave: 2 in the single-pass modes of 256-wide networks (mlp_dev.hpp gemm_layer2), so that a
 // workgroup tile is 256 samples and every weight phase - one barrier, one round of LDS-DMA, 16 KiB from L2 - is used
 // by twice as many samples
@@ -53,9 +60,9 @@ struct RenderLds {
   int32_t two_phase;
   float cam_hw, cam_hh, cam_f;
   float rays[kMaxG * 6];
-  float edgesC[kMaxGroupSamples + kMaxG];
-  float sigC[kMaxGroupSamples];
-  float wC[kMaxGroupSamples];
+  float edgesC[kMaxGroupCoarse + kMaxG];
+  float sigC[kMaxGroupCoarse];
+  float wC[kMaxGroupCoarse];
   float edgesF[kMaxGroupSamples + kMaxG];
   float sigF[kMaxGroupSamples];
   float rgbF[3 * kMaxGroupSamples];
@@ -328,6 +335,7 @@ static int launch_render(RenderKArgs k, int cus, hipStream_t s) {
   if (g < 1) g = 1;
   if (g > CAP / So) g = CAP / So;
   if (g > kMaxG) g = kMaxG;
+  if (g > kMaxGroupCoarse / k.a.S) g = kMaxGroupCoarse / k.a.S;
   if (g < 1) g = 1;
   k.G = g;
   k.nsubC = (g * k.a.S + TILE - 1) / TILE;
