@@ -17,6 +17,7 @@ FSN_PREC_FP16 = 3
 FSN_PREC_FP16X2 = 6  # two passes (weights high part only), inference only
 FSN_STATUS_FP16_RANGE = 1  # a value reached fp16 infinity
 FSN_STATUS_FP16_SMALL = 2  # a layer's activations were all below 2^-14: outside the split's float32-grade envelope
+FSN_STATUS_GRAD_RANGE = 4  # backward with per-stage scales: a stored gradient overflowed (skipped step, scale drops; no fallback)
 
 
 class MlpDesc(C.Structure):
@@ -80,7 +81,7 @@ SIGNATURES = {
     "fsn_nerf_train_workspace_floats": (_i64, [_PD, _i, _i64]),
     "fsn_nerf_train_fwd": (_i, [_PD, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "fsn_nerf_train_fwd_rays": (_i, [_PD, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
-    "fsn_nerf_train_bwd": (_i, [_PD, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "fsn_nerf_train_bwd": (_i, [_PD, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "fsn_grad_scale": (_i, [_vp, _i64, _vp, _vp]),
     "fsn_occlusion_reg_bwd": (_i, [_vp, _i64, _vp, _i64, _f, _f, _i, _vp, _vp, _vp, _vp]),
     "fsn_occgrid_march": (_i, [_vp, _vp, _i64, _vp, _i, _i, _vp, _f, _f, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

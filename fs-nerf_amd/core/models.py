@@ -93,8 +93,17 @@ class _NerfTrainFn(torch.autograd.Function):
         sink = all(getattr(p, "_fsn_grad_sink", False) and p.requires_grad and p.grad is not None and p.grad.is_contiguous()
                    and p.grad.dtype == torch.float32 and p.grad.device == d_out.device for p in ctx.params)
         into = ([p.grad for p in ctx.params[:n]], [p.grad for p in ctx.params[n:]]) if sink else None
-        dW, db = ops.nerf_train_bwd(ctx.desc, ctx.prec, ctx.weights, ctx.work, ctx.out, d_out.contiguous(), status=ctx.word,
-                                    into=into)
+        model = ctx.model
+        d_out = d_out.contiguous()
+        stage = model._bwd_stage_state(d_out.device) if model.fp16_family(ctx.prec) else None
+        if stage is not None and not model._bwd_calibrated:
+            # first backward of this model in an fp16 mode: one throw-away pass to measure the per-stage gradient
+            # magnitudes (delayed scaling needs a previous call; its own status word, scratch outputs)
+            ops.nerf_train_bwd(ctx.desc, ctx.prec, ctx.weights, ctx.work, ctx.out, d_out,
+                               status=torch.zeros_like(ctx.word) if ctx.word is not None else None, stage_state=stage)
+            model._bwd_calibrated = True
+        dW, db = ops.nerf_train_bwd(ctx.desc, ctx.prec, ctx.weights, ctx.work, ctx.out, d_out, status=ctx.word,
+                                    into=into, stage_state=stage)
         ctx.work = None
         ctx.params = None
         # fp16 range guard without a per-step host sync.  When this call's launches reported values outside the fp16
@@ -102,7 +111,6 @@ class _NerfTrainFn(torch.autograd.Function):
         # (device ops) into the device's step flag, on which FusedAdam skips the whole update - a skipped step, like a
         # loss scaler's - and into this model's own accumulated word, which the host reads every `range_check_every`
         # training calls; it then warns and continues in bf16x3.
-        model = ctx.model
         if ctx.word is not None:
             ops.step_flag(d_out.device).bitwise_or_(ctx.word)
             model._train_status(d_out.device).bitwise_or_(ctx.word)
@@ -150,6 +158,9 @@ class NeRF(nn.Module):
         self.range_check_every = 16  # ... in training: every that many steps (gradients are guarded on the device)
         self._train_calls = 0
         self._train_word: Optional[Tensor] = None
+        self._bwd_stage = None       # (scales, maxima) of the backward's delayed per-stage gradient scaling (fp16 modes)
+        self._bwd_calibrated = False
+        self.grad_overflow_looks = 0  # host looks that found a step skipped by the delayed gradient scaling
         self.train_precision: Optional[str] = None  # None: same mode as `precision`
         self.pos_mask: Optional[Tensor] = None
         self.dir_mask: Optional[Tensor] = None
@@ -171,6 +182,15 @@ class NeRF(nn.Module):
     def fp16_family(prec: int) -> bool:
         return prec in (L.FSN_PREC_FP16X3, L.FSN_PREC_FP16, L.FSN_PREC_FP16X2)
 
+    def _bwd_stage_state(self, dev):
+        """(scales, maxima) of the backward chain's delayed per-stage scaling (fsn_nerf_train_bwd), device-resident."""
+        st = self._bwd_stage
+        if st is None or st[0].device != dev:
+            n = self.n_layers + 2
+            st = self._bwd_stage = (torch.ones(n, dtype=torch.float32, device=dev), torch.zeros(n, dtype=torch.int32, device=dev))
+            self._bwd_calibrated = False
+        return st
+
     def _train_status(self, dev) -> Tensor:
         """This model's accumulated training range word (device; OR of its calls' words since the last host look)."""
         w = self._train_word
@@ -184,9 +204,12 @@ class NeRF(nn.Module):
         rank that overflowed and one that did not must not continue in different arithmetic."""
         w = self._train_status(dev)
         from ..shard import max_bits_over_ranks
+        local = int(w.item())
+        if local & L.FSN_STATUS_GRAD_RANGE:  # delayed gradient scaling skipped a step (and lowered a stage): no fall-back
+            self.grad_overflow_looks += 1
         # (MAX of bit masks 0..3: both bits lead to the same fall-back, so the largest mask is enough)
-        bits = max_bits_over_ranks(int(w.item()), dev)
-        if bits:
+        bits = max_bits_over_ranks(local & (L.FSN_STATUS_FP16_RANGE | L.FSN_STATUS_FP16_SMALL), dev)
+        if local or bits:
             w.zero_()
         return bits & (L.FSN_STATUS_FP16_RANGE | L.FSN_STATUS_FP16_SMALL)
 

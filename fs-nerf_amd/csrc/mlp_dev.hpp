@@ -389,10 +389,10 @@ __device__ __forceinline__ void range_layer_end(RangeState& r) {
 }
 
 // tell the host (never silent): bit 0 = a value reached fp16 infinity, bit 1 = a layer ran below the split's scale
-__device__ __forceinline__ void range_report(uint32_t* status, const RangeState& r) {
+__device__ __forceinline__ void range_report(uint32_t* status, const RangeState& r, uint32_t range_bit = 1u) {
   const uint32_t f = r.fall;
   const bool bad = (f & 0xffffu) >= 0x7c00u || (f >> 16) >= 0x7c00u;
-  uint32_t bits = __builtin_amdgcn_readfirstlane((int)__any(bad)) ? 1u : 0u;
+  uint32_t bits = __builtin_amdgcn_readfirstlane((int)__any(bad)) ? range_bit : 0u;
   if (__builtin_amdgcn_readfirstlane((int)r.small)) bits |= 2u;
   if (bits && status) { if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_or(status, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
@@ -614,6 +614,7 @@ __device__ __forceinline__ float relu_f32(float v) {  // on the sign bit: one v_
 struct NoHook {
   static constexpr bool kZeroInit = false;  // accumulators start from the bias
   static constexpr bool kPacked = false;    // no store<X3>(tp, frag) of the pair's 16-bit parts (training savers: true)
+  static constexpr bool kLayerEnd = false;  // no layer_end(fmax) call with the layer's packed |high part| maximum
   __device__ __forceinline__ void pre(int) {}
   __device__ __forceinline__ void post(int, float (&)[8]) {}
 };
@@ -945,7 +946,10 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
 #pragma unroll
       for (int i = 0; i < kNS; ++i) ring.cur[i] = t[i];
     }
-    if constexpr (F16 && kConverts) range_layer_end<kCheckSmall>(heads.rs);
+    if constexpr (F16 && kConverts) {
+      if constexpr (HK::kLayerEnd) hk.layer_end(heads.rs.fmax);
+      range_layer_end<kCheckSmall>(heads.rs);
+    }
     return;
   }
 #pragma unroll
@@ -1024,7 +1028,10 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
     }
     pair_epilogue<PREC, NP_OUT, EPI>(net, tp, acc0, acc1, cor0, cor1, out, heads, g, hk);
   }
-  if constexpr (F16 && kConverts) range_layer_end<kCheckSmall>(heads.rs);
+  if constexpr (F16 && kConverts) {
+    if constexpr (HK::kLayerEnd) hk.layer_end(heads.rs.fmax);
+    range_layer_end<kCheckSmall>(heads.rs);
+  }
 }
 
 template <int PREC, int NP_OUT, int KS_ACT, int KS_ENC, int EPI, int NACT, int NENC, int NOUT>

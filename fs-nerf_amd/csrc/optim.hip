@@ -34,7 +34,7 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
                        int64_t n, float step_size, float omb1, float b2, float omb2, float bc2_sqrt, float eps,
                        float wd, float grad_div, const uint32_t* __restrict__ skip_word,
                        const float* __restrict__ skip_count) {
-  if ((skip_word && (skip_word[0] & 1u)) || (skip_count && skip_count[0] > 0.f)) return;
+  if ((skip_word && (skip_word[0] & (FSN_STATUS_FP16_RANGE | FSN_STATUS_GRAD_RANGE))) || (skip_count && skip_count[0] > 0.f)) return;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
   for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
     if (i + 4 <= n) {

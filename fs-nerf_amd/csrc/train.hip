@@ -122,14 +122,17 @@ extern "C" int fsn_nerf_train_fwd_rays(const fsn_mlp_desc* desc, int prec, const
 
 extern "C" int fsn_nerf_train_bwd(const fsn_mlp_desc* desc, int prec, const float* const* W, int64_t n, float* ws,
                                   const float* out, const float* d_out, const float* grad_scale, float* const* dW,
-                                  float* const* db, int accumulate, uint32_t* status, fsn_stream_t stream) {
+                                  float* const* db, int accumulate, float* stage_scales, uint32_t* stage_amax,
+                                  uint32_t* status, fsn_stream_t stream) {
   int rc = check_desc(desc);
   if (rc != FSN_OK) return rc;
   FSN_REQUIRE(prec >= 0 && prec <= FSN_PREC_FP16, FSN_E_INVALID, "fsn_nerf_train_bwd: unknown precision");
   FSN_REQUIRE(W && dW && db, FSN_E_INVALID, "fsn_nerf_train_bwd: null pointer");
   FSN_REQUIRE(n > 0 && ws && out && d_out, FSN_E_INVALID, "fsn_nerf_train_bwd: needs the forward's workspace (n > 0)");
   FSN_REQUIRE(n < (1ll << 31), FSN_E_UNSUPPORTED, "fsn_nerf_train_bwd: n too large for one call");
-  return fused_train_bwd(desc, prec, W, n, ws, out, d_out, grad_scale, dW, db, accumulate != 0, status, as_stream(stream));
+  FSN_REQUIRE((stage_scales == nullptr) == (stage_amax == nullptr), FSN_E_INVALID, "fsn_nerf_train_bwd: stage_scales and stage_amax go together");
+  return fused_train_bwd(desc, prec, W, n, ws, out, d_out, grad_scale, dW, db, accumulate != 0, stage_scales, stage_amax, status,
+                         as_stream(stream));
 }
 
 // max |d_out| as the bits of a non-negative float (unsigned order = float order; a NaN's bits lie above infinity's and

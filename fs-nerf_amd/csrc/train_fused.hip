@@ -154,6 +154,7 @@ struct FwdSaver {
   struct Hook {
     static constexpr bool kZeroInit = false;
     static constexpr bool kPacked = true;
+    static constexpr bool kLayerEnd = false;
     uint32_t* p;    // this lane's sample at pair-row 2g of the layer's tile
     uint8_t* mk;    // this lane's 8 mask bytes (one per output pair), or null (layer without activation)
     __device__ __forceinline__ void pre(int) {}
@@ -305,23 +306,52 @@ __global__ void k_pack_bwd(BwdPackArgs a, char* __restrict__ stream, int64_t n_p
 }
 
 // ------------------------------------------------------------------ backward chain (dgrad)
+// Per-stage gradient scales (fp16 modes).  One global power of two (`grad_scale`, from max |d out|) puts the LARGEST
+// gradient of the chain into fp16's range; the pre-activation gradients of earlier layers can be orders of magnitude
+// smaller (a network shrunk by the weight-norm regulariser loses ~2 decades per layer), and below 2^-14 the high parts
+// are fp16 subnormals.  So every stored stage (dBo, d feat, dPre_{L-1} .. dPre_0) carries its own power-of-two factor
+// bs[stage] on top of grad_scale: the chain multiplies by bs[next] / bs[this] (exact) where it hands a gradient on,
+// the reduce kernels divide a stage's weight gradients by grad_scale * bs[stage].  The factors are DELAYED: each
+// backward measures every stage's largest stored |high part| (atomic maximum of the fp16 bit patterns) and
+// k_bwd_rescale moves the factor so that the next call's maximum lands at 2^5 (core/models.py keeps the two small
+// device arrays per model and calibrates them with one extra backward on first use).
+// (the maxima are collected in LDS - one ds_max per wave, stage and tile - and go to memory once, when the workgroup
+// has drained its weight stream: a global atomic inside the tile loop is a VMEM operation among the hand-counted
+// LDS-DMA loads, and made the kernel 2.3 x slower)
+__device__ __forceinline__ void stage_amax(uint32_t* amax_lds, uint32_t fmax) {
+  uint32_t m = max(fmax & 0xffffu, fmax >> 16);
+#pragma unroll
+  for (int k = 32; k >= 1; k >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, k, 64));
+  if ((threadIdx.x & 63) == 0 && m) __hip_atomic_fetch_max(amax_lds, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 struct BwdStoreHook {
   static constexpr bool kZeroInit = true;
   static constexpr bool kPacked = true;
-  uint32_t* d;  // this lane's sample at pair-row 2g of the gradient's tile
+  static constexpr bool kLayerEnd = true;
+  uint32_t* d;     // this lane's sample at pair-row 2g of the gradient's tile
+  float r;         // bs[this stage] / bs[previous stage of the chain]
+  uint32_t* amax;  // this stage's maximum word (LDS), or null
   __device__ __forceinline__ void pre(int) {}
-  __device__ __forceinline__ void post(int, float (&)[8]) {}
+  __device__ __forceinline__ void post(int, float (&v)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= r;
+  }
   template <bool X3>
   __device__ __forceinline__ void store(int tp, const Frag& o) { store_pair_parts<X3>(d, tp, o); }
+  __device__ __forceinline__ void layer_end(uint32_t fmax) { if (amax) stage_amax(amax, fmax); }
 };
 
 template <bool ADD_SIGMA>
 struct BwdMaskHook {
   static constexpr bool kZeroInit = true;
   static constexpr bool kPacked = true;
+  static constexpr bool kLayerEnd = true;
   uint32_t b0, b1;    // sign bits of the layer whose pre-activation gradient this is (FwdSaver::Hook)
   uint32_t* d;        // dPre destination (as BwdStoreHook)
-  float dsig;         // d sigma of this lane's sample
+  float r;            // bs[this stage] / bs[previous stage of the chain]
+  uint32_t* amax;     // this stage's maximum word (LDS), or null
+  float dsig;         // d sigma of this lane's sample x bs[this stage]
   const float* wsig;  // LDS: w_sigma + 4g
   __device__ __forceinline__ void pre(int) {}
   __device__ __forceinline__ void post(int tp, float (&v)[8]) {
@@ -330,9 +360,12 @@ struct BwdMaskHook {
       const f32x4 w1 = *reinterpret_cast<const f32x4*>(wsig + 32 * tp + 16);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        v[j] = v[j] + dsig * w0[j];
-        v[4 + j] = v[4 + j] + dsig * w1[j];
+        v[j] = v[j] * r + dsig * w0[j];
+        v[4 + j] = v[4 + j] * r + dsig * w1[j];
       }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= r;
     }
     const uint32_t bits = (tp < 4 ? b0 : b1) >> (8 * (tp & 3));
 #pragma unroll
@@ -340,6 +373,7 @@ struct BwdMaskHook {
   }
   template <bool X3>
   __device__ __forceinline__ void store(int tp, const Frag& o) { store_pair_parts<X3>(d, tp, o); }
+  __device__ __forceinline__ void layer_end(uint32_t fmax) { if (amax) stage_amax(amax, fmax); }
 };
 
 struct TrainBwdArgs {
@@ -350,15 +384,23 @@ struct TrainBwdArgs {
   const float *out, *d_out, *scale;
   float* ws;
   int64_t off_h, h_stride, off_bo, off_dhead, off_dbo, off_dp, off_mask, mask_stride;
+  const float* bscale;  // per-stage factors bs[0..L] (dPre_0..dPre_{L-1}, d feat), bs[L+1] (dBo); null: all 1
+  uint32_t* bamax;      // per-stage maxima of the stored |high parts| (fp16 bit patterns), or null
 };
 
 template <int NT, int PREC>
 __global__ __launch_bounds__(kThreads) void k_train_bwd(TrainBwdArgs a) {
   constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
-  __shared__ __attribute__((aligned(1024))) char smem[kRingBytes + (kAuxCapFloats + 96) * 4];
+  __shared__ __attribute__((aligned(1024))) char smem[kRingBytes + (kAuxCapFloats + 96 + 2 * (kMaxLayers + 2)) * 4];
   float* aux_lds = reinterpret_cast<float*>(smem + kRingBytes);
+  float* bs_lds = aux_lds + kAuxCapFloats + 96;                                // per-stage factors
+  uint32_t* am_lds = reinterpret_cast<uint32_t*>(bs_lds + (kMaxLayers + 2));  // per-stage maxima of this workgroup
   NetDev net;
   load_net(a.net, nullptr, nullptr, aux_lds, net);
+  if (threadIdx.x < kMaxLayers + 2) {
+    bs_lds[threadIdx.x] = (F16 && a.bscale && (int)threadIdx.x < a.net.n_layers + 2) ? a.bscale[threadIdx.x] : 1.0f;
+    am_lds[threadIdx.x] = 0u;
+  }
   __syncthreads();
   constexpr int D = 32 * NT;
   const int L = net.n_layers;
@@ -395,10 +437,17 @@ __global__ __launch_bounds__(kThreads) void k_train_bwd(TrainBwdArgs a) {
     const int64_t lane_off_h = tile * (D / 2) * kTC + t_layout_off(NPL, D / 4, 2 * g, col);  // ... of a D/2-row tile
     Frag A[NT], B[NT];
     const uint32_t* mk = reinterpret_cast<const uint32_t*>(a.ws + a.off_mask) + ((tile * 4 + g) * kTC + col) * 2;
+    // per-stage factors (wave-uniform scalar loads; all 1 in the bf16 modes / without the arrays)
+    auto bs = [&](int i) { return bs_lds[i]; };
+    auto am = [&](int i) { return (F16 && a.bamax) ? am_lds + i : nullptr; };
     {  // branch output: d Bo = W_rgb^T dz, masked by Bo > 0 (models.py:133-134), VALU
       const uint32_t bbits = mk[L * a.mask_stride];
       uint32_t* dbo = wsu + a.off_dbo + lane_off_h;
       const float* wr = net.aux + (L + 3) * D + 4 * g;
+      const float s_bo = bs(L + 1);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dz[c] *= s_bo;  // (dhead above holds the unscaled dz)
+      uint32_t fm = 0u;
 #pragma unroll
       for (int ks = 0; ks < NT / 2; ++ks) {
         float v[8];
@@ -414,11 +463,16 @@ __global__ __launch_bounds__(kThreads) void k_train_bwd(TrainBwdArgs a) {
           }
         }
         split_store<F16, X3>(v, B[ks]);
+        if constexpr (F16) range_track<true>(fm, B[ks].hi);
         store_pair_parts<X3>(dbo, ks, B[ks]);
+      }
+      if constexpr (F16) {
+        if (uint32_t* w = am(L + 1)) stage_amax(w, fm);
+        asm("v_pk_max_u16 %0, %0, %1" : "+v"(heads.rs.fall) : "v"(fm));  // (an overflow here is reported like any other)
       }
     }
     {  // d feat = W_branch[:, :D]^T dBo  -> "dPre" of the connection (no activation, models.py:130)
-      BwdStoreHook hk{wsu + a.off_dp + L * a.h_stride + lane_off};
+      BwdStoreHook hk{wsu + a.off_dp + L * a.h_stride + lane_off, bs(L) / bs(L + 1), am(L)};
       gemm_layer<PREC, NT, NT / 2, 0, EPI_CVT>(st, net, 0, B, none, A, heads, ring, g, hk);
     }
     {  // d h_{L-1} = W_conn^T d feat + d sigma w_sigma, masked by h_{L-1} > 0
@@ -426,7 +480,9 @@ __global__ __launch_bounds__(kThreads) void k_train_bwd(TrainBwdArgs a) {
       hk.b0 = mk[(L - 1) * a.mask_stride];
       hk.b1 = mk[(L - 1) * a.mask_stride + 1];
       hk.d = wsu + a.off_dp + (L - 1) * a.h_stride + lane_off;
-      hk.dsig = dsig;
+      hk.r = bs(L - 1) / bs(L);
+      hk.amax = am(L - 1);
+      hk.dsig = dsig * bs(L - 1);
       hk.wsig = net.aux + (L + 2) * D + 4 * g;
       gemm_layer<PREC, NT, NT, 0, EPI_CVT>(st, net, 0, A, none, B, heads, ring, g, hk);
     }
@@ -437,22 +493,34 @@ __global__ __launch_bounds__(kThreads) void k_train_bwd(TrainBwdArgs a) {
         hk.b0 = mk[(l - 1) * a.mask_stride];
         hk.b1 = mk[(l - 1) * a.mask_stride + 1];
         hk.d = wsu + a.off_dp + (l - 1) * a.h_stride + lane_off;
-          gemm_layer<PREC, NT, NT, 0, EPI_CVT>(st, net, 0, B, none, A, heads, ring, g, hk);
+        hk.r = bs(l - 1) / bs(l);
+        hk.amax = am(l - 1);
+        gemm_layer<PREC, NT, NT, 0, EPI_CVT>(st, net, 0, B, none, A, heads, ring, g, hk);
       }
       if (l - 1 >= 1) {
         BwdMaskHook<false> hk;
         hk.b0 = mk[(l - 2) * a.mask_stride];
         hk.b1 = mk[(l - 2) * a.mask_stride + 1];
         hk.d = wsu + a.off_dp + (l - 2) * a.h_stride + lane_off;
-          gemm_layer<PREC, NT, NT, 0, EPI_CVT>(st, net, 0, A, none, B, heads, ring, g, hk);
+        hk.r = bs(l - 2) / bs(l - 1);
+        hk.amax = am(l - 2);
+        gemm_layer<PREC, NT, NT, 0, EPI_CVT>(st, net, 0, A, none, B, heads, ring, g, hk);
       }
     }
     if constexpr (F16) {  // a scaled gradient left the fp16 range
       range_layer_end<false>(heads.rs);
-      range_report(net.status, heads.rs);
+      // with per-stage scales an overflowing gradient is an event of the delayed scaling (FSN_STATUS_GRAD_RANGE: the
+      // step is skipped, k_bwd_rescale lowers the stage), without them a range failure like the forward's
+      range_report(net.status, heads.rs, a.bscale ? FSN_STATUS_GRAD_RANGE : FSN_STATUS_FP16_RANGE);
     }
   }
   st.drain();
+  if constexpr (F16) {
+    if (a.bamax) {
+      __syncthreads();
+      if ((int)threadIdx.x < L + 2 && am_lds[threadIdx.x]) atomicMax(a.bamax + threadIdx.x, am_lds[threadIdx.x]);
+    }
+  }
 }
 
 // ------------------------------------------------------------------ wgrad
@@ -845,12 +913,14 @@ struct RdJob {
   float* db;
   int32_t a_rows, b_rows, ld, col0, mode, n_freqs;  // mode 0: column = col0 + c; 1/2: position/direction slots
   int32_t nsplit;
+  int32_t stage;  // index of the job's gradient operand in the per-stage factors (RdArgs::bscale)
 };
 struct RdArgs {
   RdJob job[2 * kMaxLayers + 4];
   const float* scale;
   const uint32_t* status;  // fp16 modes: this call's range-guard word (null in the bf16 modes); bit 0 -> zero gradients
   int32_t accumulate;      // add to dW / db instead of overwriting them
+  const float* bscale;     // per-stage factors of the backward chain (fp16 modes) or null
 };
 
 // Sum of the split-K partials of one element in a FIXED order (deterministic): eight independent running sums over
@@ -870,11 +940,11 @@ __device__ __forceinline__ float sum_partials(const float* __restrict__ p0, int6
 __global__ void k_wgrad_reduce(RdArgs a) {
   const RdJob jb = a.job[blockIdx.y];
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  const float inv = a.scale ? 1.0f / a.scale[0] : 1.0f;
+  const float inv = (a.scale ? 1.0f / a.scale[0] : 1.0f) / (a.bscale ? a.bscale[jb.stage] : 1.0f);  // (powers of two)
   // The forward / backward launch of THIS call reported values outside the fp16 range (bit 0 of the per-call word):
   // the sums are inf / NaN.  The gradients are zeroed ON THE DEVICE, without a host sync; fsn_adam_step skips the
   // update on the same word, and the host learns of it at its next (amortised) look and continues in bf16x3.
-  const bool skip = a.status && (a.status[0] & 1u);
+  const bool skip = a.status && (a.status[0] & (FSN_STATUS_FP16_RANGE | FSN_STATUS_GRAD_RANGE));
   const int tot = jb.a_rows * jb.b_rows;
   if (e < tot) {
     const int row = e / jb.b_rows, c = e - row * jb.b_rows;
@@ -1034,13 +1104,35 @@ __global__ void k_heads_reduce(HeadsRdArgs a) {
   if (e >= n) return;
   const float inv = a.scale ? 1.0f / a.scale[0] : 1.0f;
   float sum = sum_partials(a.hpart + e, n, a.nsplit) * inv;
-  if (a.status && (a.status[0] & 1u)) sum = 0.f;
+  if (a.status && (a.status[0] & (FSN_STATUS_FP16_RANGE | FSN_STATUS_GRAD_RANGE))) sum = 0.f;
   float* dst;
   if (e < a.D) dst = a.dWs + e;
   else if (e < a.D + 3 * (a.D / 2)) dst = a.dWr + (e - a.D);
   else if (e < n - 1) dst = a.dbr + (e - a.D - 3 * (a.D / 2));
   else dst = a.dbs;
   *dst = a.accumulate ? *dst + sum : sum;
+}
+
+// Delayed per-stage scaling (see BwdStoreHook): after a backward, move every stage's factor so that the largest stored
+// |high part| it just produced would have been 2^5 (eleven octaves of headroom to 65504 for the next batch - a stage's
+// maximum moved by 2^8 between two consecutive batches early in a run - and 19 below it to 2^-14, under which the
+// scaled low parts still resolve 2^-41 of the maximum); a stage that overflowed (maximum = infinity, the step is a
+// skipped one) drops by 2^8, a stage that stored only zeros keeps its factor.  Factors stay powers of two in [2^-24, 2^40]; the maxima are cleared for the next call.
+__global__ void k_bwd_rescale(float* __restrict__ bs, uint32_t* __restrict__ amax, int n) {
+  const int i = threadIdx.x;
+  if (i >= n) return;
+  const uint32_t m = amax[i];
+  amax[i] = 0u;
+  if (m == 0u) return;
+  float f = bs[i];
+  if (m >= 0x7c00u) {
+    f *= 0.00390625f;
+  } else {
+    // floor(log2) of the fp16 value with bit pattern m (subnormals: below 2^-14, counted from their leading bit)
+    const int e = (m >> 10) ? (int)(m >> 10) - 15 : (31 - __builtin_clz(m)) - 24;
+    f = ldexpf(f, 5 - e);
+  }
+  bs[i] = fminf(fmaxf(f, 5.9604644775390625e-08f), 1.099511627776e12f);
 }
 
 // ------------------------------------------------------------------ host side
@@ -1125,7 +1217,7 @@ int fused_train_fwd(const fsn_mlp_desc* d, int prec, const float* const* W, cons
 
 int fused_train_bwd(const fsn_mlp_desc* d, int prec, const float* const* W, int64_t n, float* ws, const float* out,
                     const float* d_out, const float* grad_scale_dev, float* const* dW, float* const* db,
-                    bool accumulate, uint32_t* status, hipStream_t s) {
+                    bool accumulate, float* bscale, uint32_t* bamax, uint32_t* status, hipStream_t s) {
   FusedLayout F;
   const char* why;
   int rc = make_fused_layout(*d, prec, n, F, &why);
@@ -1154,7 +1246,8 @@ int fused_train_bwd(const fsn_mlp_desc* d, int prec, const float* const* W, int6
   // ---- dgrad chain
   {
     TrainBwdArgs a{net_params(*d, G, ws + F.blob_f, status), reinterpret_cast<const char*>(ws + F.blob_b), F.nph_bwd, n, out, d_out,
-                   grad_scale_dev, ws, F.h, F.h_stride, F.bo, F.dhead, F.dbo, F.dp, F.mask, F.mask_stride};
+                   grad_scale_dev, ws, F.h, F.h_stride, F.bo, F.dhead, F.dbo, F.dp, F.mask, F.mask_stride,
+                   prec_is_f16(prec) ? bscale : nullptr, prec_is_f16(prec) ? bamax : nullptr};
     const unsigned grid = (unsigned)(F.T < cus ? F.T : cus);
     const int key = (D == 256 ? 4 : 0) + prec;
     switch (key) {
@@ -1178,8 +1271,8 @@ int fused_train_bwd(const fsn_mlp_desc* d, int prec, const float* const* W, int6
   auto U = [](const float* q) { return reinterpret_cast<const uint32_t*>(q); };  // saved tensors: packed T-layout
   auto H = [&](int i) { return ws + F.h + i * F.h_stride; };
   auto dP = [&](int i) { return ws + F.dp + i * F.h_stride; };
-  auto add = [&](int kind, const float* A, const float* B, int a_rows, int b_rows, bool bias, float* dWp, float* dbp, int ld,
-                 int col0, int mode, int n_freqs) {
+  auto add = [&](int kind, int stage, const float* A, const float* B, int a_rows, int b_rows, bool bias, float* dWp, float* dbp,
+                 int ld, int col0, int mode, int n_freqs) {
     const int64_t ns = F.nsplit[kind];
     WgJob& j = wa[kind].job[cnt[kind]++];
     j.A = U(A); j.B = U(B); j.b_rows = b_rows; j.a_rows = a_rows;
@@ -1188,17 +1281,17 @@ int fused_train_bwd(const fsn_mlp_desc* d, int prec, const float* const* W, int6
     if (bias) { j.bpart = part; part += ns * a_rows; }
     RdJob& r = rd.job[nrd++];
     r.part = j.part; r.bpart = j.bpart; r.dW = dWp; r.db = dbp; r.a_rows = a_rows; r.b_rows = b_rows; r.ld = ld;
-    r.col0 = col0; r.mode = mode; r.n_freqs = n_freqs; r.nsplit = (int)ns;
+    r.col0 = col0; r.mode = mode; r.n_freqs = n_freqs; r.nsplit = (int)ns; r.stage = stage;
   };
   for (int l = 1; l < L; ++l) {
     const bool wide = (d->skip_mask >> (l - 1)) & 1u;
-    add(WG_BIG, dP(l), H(l - 1), D, D, true, dW[l], db[l], D + (wide ? F.d_pe : 0), 0, 0, 0);
-    if (wide) add(WG_ENC, dP(l), ws + F.pe, D, 64, false, dW[l], nullptr, D + F.d_pe, D, 1, d->n_freqs_pos);
+    add(WG_BIG, l, dP(l), H(l - 1), D, D, true, dW[l], db[l], D + (wide ? F.d_pe : 0), 0, 0, 0);
+    if (wide) add(WG_ENC, l, dP(l), ws + F.pe, D, 64, false, dW[l], nullptr, D + F.d_pe, D, 1, d->n_freqs_pos);
   }
-  add(WG_BIG, dP(L), H(L - 1), D, D, true, dW[L + 1], db[L + 1], D, 0, 0, 0);
-  add(WG_ENC, dP(0), ws + F.pe, D, 64, true, dW[0], db[0], F.d_pe, 0, 1, d->n_freqs_pos);
-  add(WG_BR, ws + F.dbo, H(L), D / 2, D, true, dW[L + 2], db[L + 2], D + F.d_de, 0, 0, 0);
-  add(WG_BD, ws + F.dbo, ws + F.de, D / 2, 32, false, dW[L + 2], nullptr, D + F.d_de, D, 2, d->n_freqs_dir);
+  add(WG_BIG, L, dP(L), H(L - 1), D, D, true, dW[L + 1], db[L + 1], D, 0, 0, 0);
+  add(WG_ENC, 0, dP(0), ws + F.pe, D, 64, true, dW[0], db[0], F.d_pe, 0, 1, d->n_freqs_pos);
+  add(WG_BR, L + 1, ws + F.dbo, H(L), D / 2, D, true, dW[L + 2], db[L + 2], D + F.d_de, 0, 0, 0);
+  add(WG_BD, L + 1, ws + F.dbo, ws + F.de, D / 2, 32, false, dW[L + 2], nullptr, D + F.d_de, D, 2, d->n_freqs_dir);
   FSN_REQUIRE(part - (ws + F.part) <= part_floats(*d, F.nsplit), FSN_E_HIP, "internal: wgrad partial area");
   for (int k = 0; k < 4; ++k) { wa[k].T = F.T; wa[k].nsplit = F.nsplit[k]; }
   const WgArgs &big = wa[WG_BIG], &enc = wa[WG_ENC], &br = wa[WG_BR], &bd = wa[WG_BD];
@@ -1222,6 +1315,7 @@ int fused_train_bwd(const fsn_mlp_desc* d, int prec, const float* const* W, int6
   rd.scale = grad_scale_dev;
   rd.status = prec_is_f16(prec) ? status : nullptr;  // (only the fp16 modes can overflow)
   rd.accumulate = accumulate ? 1 : 0;
+  rd.bscale = prec_is_f16(prec) ? bscale : nullptr;
   {
     dim3 grid((unsigned)((D * D + 255) / 256), (unsigned)nrd);
     k_wgrad_reduce<<<grid, 256, 0, s>>>(rd);
@@ -1247,6 +1341,10 @@ int fused_train_bwd(const fsn_mlp_desc* d, int prec, const float* const* W, int6
     const int nn = D + 3 * (D / 2) + 4;
     k_heads_reduce<<<(unsigned)((nn + 255) / 256), 256, 0, s>>>(hr);
     FSN_LAUNCH_CHECK("k_heads_reduce");
+  }
+  if (prec_is_f16(prec) && bscale && bamax) {
+    k_bwd_rescale<<<1, 64, 0, s>>>(bscale, bamax, L + 2);
+    FSN_LAUNCH_CHECK("k_bwd_rescale");
   }
   return FSN_OK;
 }

@@ -15,6 +15,6 @@ int fused_train_fwd(const fsn_mlp_desc* d, int prec, const float* const* W, cons
                     uint32_t* status, hipStream_t s, const TrainRays* rays = nullptr);
 int fused_train_bwd(const fsn_mlp_desc* d, int prec, const float* const* W, int64_t n, float* ws, const float* out,
                     const float* d_out, const float* grad_scale_dev, float* const* dW, float* const* db,
-                    bool accumulate, uint32_t* status, hipStream_t s);
+                    bool accumulate, float* bscale, uint32_t* bamax, uint32_t* status, hipStream_t s);
 
 }  // namespace fsn

@@ -631,10 +631,13 @@ def grad_scale_for(d_out: Tensor) -> Tensor:
 
 
 def nerf_train_bwd(desc: L.MlpDesc, prec: int, weights: Sequence[Tensor], work: Tensor, out: Tensor, d_out: Tensor,
-                   status: Optional[Tensor] = None, into: Optional[Tuple[Sequence[Tensor], Sequence[Tensor]]] = None):
+                   status: Optional[Tensor] = None, into: Optional[Tuple[Sequence[Tensor], Sequence[Tensor]]] = None,
+                   stage_state: Optional[Tuple[Tensor, Tensor]] = None):
     """-> (d_weights, d_biases) lists in state_dict order.  `status`: the word given to nerf_train_fwd.
     `into` = (weight .grad buffers, bias .grad buffers): the gradients are ADDED to them on the device (what autograd's
-    AccumulateGrad does with returned tensors, without the temporaries and one add launch per parameter); -> into."""
+    AccumulateGrad does with returned tensors, without the temporaries and one add launch per parameter); -> into.
+    `stage_state` = (scales float32 [n_layers + 2], maxima int32 [n_layers + 2]), fp16 modes: the backward chain's delayed
+    per-stage power-of-two factors (include/fsnerf_hip.h); the call uses the scales and updates them for the next one."""
     ws_ = [_f32(w.detach(), "weight") for w in weights]
     d_out = _f32(d_out, "d_out").reshape(-1, 4)
     n = d_out.shape[0]
@@ -657,7 +660,8 @@ def nerf_train_bwd(desc: L.MlpDesc, prec: int, weights: Sequence[Tensor], work: 
     with torch.cuda.device(work.device):
         L.check(L.lib().fsn_nerf_train_bwd(C.byref(desc), prec, _ptr_array(ws_), n, _p(work), _p(out), _p(d_out),
                                            _p(scale), _ptr_array(dW), _ptr_array(db), 0 if into is None else 1,
-                                           _p(status), _stream()),
+                                           _p(stage_state[0]) if stage_state else None,
+                                           _p(stage_state[1]) if stage_state else None, _p(status), _stream()),
                 "fsn_nerf_train_bwd")
     return dW, db
 

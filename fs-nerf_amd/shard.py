@@ -115,7 +115,7 @@ class FlatGrads:
             self.flag_slot.fill_(float(flag))
         elif self._buf.is_cuda:  # this rank's step flag (device word of the training launches) into the bucket's slot
             from . import ops
-            self.flag_slot.copy_((ops.step_flag(self._buf.device) & 1).to(torch.float32))
+            self.flag_slot.copy_((ops.step_flag(self._buf.device) & 5).to(torch.float32))  # FSN_STATUS_FP16_RANGE | _GRAD_RANGE
         flat = self._buf
         if flat.is_cuda and dist.get_backend() == "gloo":  # CPU rehearsal backend: stage through host memory
             host = flat.cpu()

@@ -56,6 +56,9 @@ typedef void* fsn_stream_t; /* hipStream_t */
  * re-runs in FSN_PREC_BF16X3).  The bf16 modes set neither bit. */
 #define FSN_STATUS_FP16_RANGE 1u
 #define FSN_STATUS_FP16_SMALL 2u
+#define FSN_STATUS_GRAD_RANGE 4u /* fsn_nerf_train_bwd with stage_scales: a stored gradient reached fp16 infinity - the
+                                   call's gradients are zeroed, fsn_adam_step skips the update, the stage's scale drops
+                                   (an event of the delayed gradient scaling like a loss scaler's, not a range fallback) */
 
 int fsn_version(void);
 const char* fsn_last_error(void);
@@ -291,10 +294,16 @@ int fsn_nerf_train_fwd_rays(const fsn_mlp_desc* desc, int prec, const float* con
                             float* workspace, float* out, uint32_t* status, fsn_stream_t stream);
 /* accumulate != 0: the gradients are ADDED to d_weights / d_biases (the caller's .grad buffers: what autograd's
  * AccumulateGrad would do with a returned tensor, without the temporaries and the 24 add launches per step);
- * 0: they are overwritten.  A flagged call (bit 0 of *status) contributes zeros either way. */
+ * 0: they are overwritten.  A flagged call (bit 0 of *status) contributes zeros either way.
+ * stage_scales / stage_amax (both or neither; fp16 modes): n_layers + 2 device floats, initially 1.0, and as many zeroed
+ * device words - the backward chain's per-stage power-of-two factors on top of grad_scale and the maxima they are
+ * steered by.  The call uses the factors it finds and leaves the ones for the NEXT call (delayed scaling): a network
+ * whose layer gradients span more than fp16's range (weight-norm regularised ones do) keeps float32-grade weight
+ * gradients from the second call on; run one throw-away call to calibrate a fresh pair of arrays. */
 int fsn_nerf_train_bwd(const fsn_mlp_desc* desc, int prec, const float* const* weights, int64_t n, float* workspace,
                        const float* out, const float* d_out, const float* grad_scale, float* const* d_weights,
-                       float* const* d_biases, int accumulate, uint32_t* status, fsn_stream_t stream);
+                       float* const* d_biases, int accumulate, float* stage_scales, uint32_t* stage_amax,
+                       uint32_t* status, fsn_stream_t stream);
 /* The power-of-two `grad_scale` of the fp16 modes' backward in one launch: 2^floor(log2(1024 / max|d_out|)), exponent
  * clamped to [-40, 60], 1 when the maximum is 0 / inf / NaN (the arithmetic of ops.grad_scale_for, which took nine
  * elementwise / reduction launches).  buf: 4 device floats, ZEROED by the caller; buf[0] receives the scale (buf[1..2]
@@ -311,8 +320,8 @@ int fsn_composite_packed_bwd(const float* sigmas, const float* rgbs, const float
  * fsn_adam_step: torch.optim.Adam's update (no amsgrad), operation for operation in float32, one launch over the
  *   arena: params / grads / exp_avg / exp_avg_sq [n]; `step` = 1, 2, ... (bias corrections are formed in double on
  *   the host); grad_div divides the gradient first (pass the number of ranks when `grads` holds an all-reduced SUM).
- *   skip_word / skip_count (DEVICE pointers or NULL): the launch leaves parameters and moments untouched when bit 0
- *   of *skip_word is set or *skip_count > 0 - the per-step status word of fsn_nerf_train_fwd/_bwd (fp16 overflow in
+ *   skip_word / skip_count (DEVICE pointers or NULL): the launch leaves parameters and moments untouched when
+ *   FSN_STATUS_FP16_RANGE or FSN_STATUS_GRAD_RANGE is set in *skip_word or *skip_count > 0 - the per-step status word of fsn_nerf_train_fwd/_bwd (fp16 overflow in
  *   this step) and the flag slot of an all-reduced gradient bucket; decided on the device, no host sync.
  * fsn_weight_norm_*: the weight-norm "frequency" regulariser of run-nerf.py:266-279: out = sum over the selected
  *   tensors (segments [off, off+len) of the arena, HOST tables, <= 40) of |w|_1 (l2 = 0) or |w|_2 (l2 = 1).

@@ -58,7 +58,7 @@ def test_training_and_occgrid_entry_points_validate_without_gpu():
     assert lib.fsn_nerf_train_workspace_floats(C.byref(d), 9, n) < 0 and b"precision" in lib.fsn_last_error()
     assert lib.fsn_nerf_train_workspace_floats(C.byref(d), L.FSN_PREC_FP16X3, -1) < 0
     assert lib.fsn_nerf_train_fwd(C.byref(d), 7, None, None, None, None, None, None, 4, None, None, None, None) != 0
-    assert lib.fsn_nerf_train_bwd(C.byref(d), L.FSN_PREC_FP16X3, None, 0, None, None, None, None, None, None, 0, None, None) != 0
+    assert lib.fsn_nerf_train_bwd(C.byref(d), L.FSN_PREC_FP16X3, None, 0, None, None, None, None, None, None, 0, None, None, None, None) != 0
     assert lib.fsn_grad_scale(None, 5, None, None) != 0 and b"fsn_grad_scale" in lib.fsn_last_error()
     # the two-pass mode is inference only
     assert lib.fsn_nerf_train_fwd(C.byref(d), L.FSN_PREC_FP16X2, None, None, None, None, None, None, 4, None, None, None, None) != 0

@@ -715,3 +715,54 @@ def test_training_sampler_overflow_joins_the_step_guard_without_a_host_read():
     step()  # bf16x3: finite gradients, an update
     assert all(bool(torch.isfinite(p.grad).all()) for p in m.parameters())
     assert int(ops.step_flag(dev).item()) == 0
+
+
+@pytest.mark.gpu
+def test_backward_stage_scales_adapt_and_an_overflowing_stage_is_a_skipped_step():
+    """Delayed per-stage gradient scaling (fsn_nerf_train_bwd, stage_scales): (a) the factors settle so that every stage's
+    largest stored gradient sits near 2^5 whatever d(out)'s size; (b) factors that are far too large make the backward
+    overflow - FSN_STATUS_GRAD_RANGE: zero gradients, the step flag raised for the optimizer, NO range fall-back - and
+    the factors drop until the gradients are right again."""
+    from fs_nerf_amd import ops, _lib as Lb
+    from fs_nerf_amd.core.models import NeRF
+    dev = torch.device("cuda:0")
+    L, D, N = 8, 256, 640
+    sd = O.init_nerf_state_dict(L, D, [4], 10, 4, seed=3)
+    sd["sigma.weight"] *= 16.0
+    m = NeRF(3, 3, L, D, (4,), pos_fn={"n_freqs": 10, "log_space": True}, dir_fn={"n_freqs": 4, "log_space": True})
+    m.load_state_dict(sd)
+    m = m.to(dev).train()
+    m.range_check_every = 1
+    gen = torch.Generator().manual_seed(0)
+    x = (torch.rand(N, 3, generator=gen) * 2 - 1).to(dev)
+    d = torch.nn.functional.normalize(torch.randn(N, 3, generator=gen), dim=-1).to(dev)
+    c = torch.randn(N, 4, generator=gen).to(dev)
+    ops.step_flag(dev).zero_()
+
+    def grads(cs):
+        m.zero_grad(set_to_none=True)
+        (m(x, d) * (c * cs)).sum().backward()
+        return [p.grad.clone() for p in m.parameters()]
+
+    g1 = grads(1.0)
+    scales = m._bwd_stage[0].clone()
+    assert float(scales[0]) >= 16.0 * float(scales[L - 1]), scales  # gradients shrink on the way back: earlier layers need more
+    g2 = grads(1e-6)  # grad_scale absorbs d(out)'s size: same per-stage factors, gradients scale exactly
+    assert bool((torch.log2(m._bwd_stage[0] / scales).abs() <= 1.0).all())
+    for a, b in zip(g1, g2):
+        assert float((a * 1e-6 - b).abs().max()) <= 2e-4 * float(b.abs().max())
+    # (b) absurd factors: the next backward overflows and is a skipped step, not a precision fall-back
+    m._bwd_stage[0].fill_(2.0 ** 34)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        bad = grads(1.0)
+        assert all(float(g.abs().max()) == 0.0 for g in bad)
+        assert int(ops.step_flag(dev).item()) & Lb.FSN_STATUS_GRAD_RANGE and m.precision == "fp16x3"
+        ops.step_flag(dev).zero_()
+        for _ in range(6):  # 2^34 -> 2^26 -> ... until nothing overflows and the measured maxima take over
+            g = grads(1.0)
+            ops.step_flag(dev).zero_()
+    assert m.precision == "fp16x3" and m.grad_overflow_looks >= 1
+    for a, b in zip(g1, g):
+        assert float((a - b).abs().max()) <= 2e-4 * float(a.abs().max())

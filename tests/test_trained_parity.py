@@ -201,6 +201,61 @@ def test_packed_occupancy_path_on_trained_weights(dev, students, which):
     STATS.setdefault("packed", {})[f"{which}_samples_per_ray"] = float(ri.numel()) / R
 
 
+def _relative_relu_margin(sd, x, d):
+    """min over the ReLU layers of (smallest |pre-activation| of the sample / largest |pre-activation| of the LAYER over
+    the batch): the shrunk students' layers live on very different scales (1e-4 .. 1), and a unit whose pre-activation
+    is within the forward's RELATIVE error of zero takes the other branch in one of the two computations (float64, CPU)."""
+    sd = {k: v.double() for k, v in sd.items()}
+    pe = O.posenc(x.double(), 10, True)
+    h, margin = pe, torch.full((x.shape[0],), 1e9, dtype=torch.float64)
+    for i in range(L):
+        z = torch.nn.functional.linear(h, sd[f"layers.{i}.weight"], sd[f"layers.{i}.bias"])
+        margin = torch.minimum(margin, z.abs().amin(dim=1) / z.abs().max())
+        h = torch.relu(z)
+        if i == 4:
+            h = torch.cat([h, pe], dim=-1)
+    f = torch.nn.functional.linear(h, sd["connection.weight"], sd["connection.bias"])
+    zb = torch.nn.functional.linear(torch.cat([f, O.posenc(d.double(), 4, True)], dim=-1), sd["branch.weight"], sd["branch.bias"])
+    return torch.minimum(margin, zb.abs().amin(dim=1) / zb.abs().max())
+
+
+@pytest.mark.parametrize("which", ["plain", "wnorm_l1", "wnorm_l2"])
+def test_parameter_gradients_on_trained_weights(dev, students, which):
+    """fsn_nerf_train_fwd/_bwd on the trained students (dead units, shrunk weights, activations of ~0.06 under the l1
+    regulariser): every parameter gradient within 2e-4 of the tensor's largest entry against float64 autograd on the
+    oracle - the bar the freshly initialised networks of test_train_step.py are held to."""
+    from test_train_step import _rel
+    sd = students[which]
+    m = hip_model(sd, L, D, dev, "fp16x3").train()
+    gen = torch.Generator().manual_seed(11)
+    N = 777
+    x = torch.rand(16 * N, 3, generator=gen) * 3.0 - 1.5
+    d = torch.nn.functional.normalize(torch.randn(16 * N, 3, generator=gen), dim=-1)
+    keep = _relative_relu_margin(sd, x, d) > 2e-5
+    x, d = x[keep][:N].contiguous(), d[keep][:N].contiguous()
+    assert x.shape[0] == N, int(keep.sum())
+    c = torch.randn(N, 4, generator=gen)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        out = m(x.to(dev), d.to(dev))
+        (out * c.to(dev)).sum().backward()
+    assert m.precision == "fp16x3"
+    sdr = {k: v.detach().double().clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.nerf_forward(sdr, x.double(), d.double(), **cfg_of(L))
+    (ref * c.double()).sum().backward()
+    # yardstick: the same gradients by float32 autograd on the oracle
+    sd32 = {k: v.detach().float().clone().requires_grad_(True) for k, v in sd.items()}
+    (O.nerf_forward(sd32, x.float(), d.float(), **cfg_of(L)) * c.float()).sum().backward()
+    worst, report = {}, {}
+    for name, p in m.named_parameters():
+        worst[name] = _rel(p.grad, sdr[name].grad)
+        report[name] = (worst[name], _rel(sd32[name].grad, sdr[name].grad))
+    STATS.setdefault("gradients", {})[which] = {"worst": max(worst.values()), "where": max(worst, key=worst.get),
+                                                "fp32_autograd_there": report[max(worst, key=worst.get)][1]}
+    bad = {n: v for n, v in report.items() if v[0] >= max(2e-4, 3.0 * v[1])}
+    assert not bad, (which, bad)
+
+
 def test_zz_record_stats(dev, students):
     """(last in the file) write what the tests above measured next to the GPU run's other outputs"""
     assert all(n in STATS for n in ("plain", "wnorm_l1", "wnorm_l2"))
