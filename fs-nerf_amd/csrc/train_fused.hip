@@ -753,6 +753,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_wgrad(WgArgs a) {  // (2 waves p
   const int lane_off = X3 ? (m >> 3) * 1024 + ((m & 7) + 8 * (kg ^ ((m >> 4) & 1))) * 16 : (m >> 4) * 1024 + (kg * 16 + (m & 15)) * 16;
   Frag af[2];    // current chunk: the wave's A rows, tile 0 (even rows) / tile 1 (odd rows)
   Frag bfr[BT];  // ... its B tiles
+  s16x8 ahs[2];  // fp16 x3: A's high parts x 2^-11 (operand of the A-high x B-low product)
   u32x4 rawA[NG], rawB[NBP][NG];  // samples 8 kg .. + 8 of the lane's pair-row: NG granules per section
   // One step = [wait + barrier: chunk ci+1 landed, slot of chunk ci free] [refill that slot] [raw reads of chunk ci+1]
   // [MFMAs of chunk ci] [unzip chunk ci+1].  ACT / BIAS (wave-uniform) are compile-time inside the loops so that the
@@ -773,7 +774,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_wgrad(WgArgs a) {  // (2 waves p
     }
   };
   // the operands of the even-row and the odd-row tile out of a section's granules
-  auto unzip_section = [&](const u32x4 (&g)[NG], Frag& ev, Frag& od) {
+  // fp16 x3: the low parts arrive scaled by 2^11.  A's are unscaled here (A = the gradients, which the backward keeps
+  // near 2^5: its low parts stay normal numbers).  B's - the forward's activations, of any size down to 2^-14 - are
+  // NOT: their product takes the 2^-11 on the A side instead (ahs = A's high parts x 2^-11, at most 2^-6; what that
+  // loses below 2^-14 is 2^-30 of the largest product), so a layer with activations of 1e-3 keeps its low parts' bits.
+  auto unzip_section = [&](const u32x4 (&g)[NG], Frag& ev, Frag& od, auto IS_A) {
+    constexpr bool kUnscale = F16 && decltype(IS_A)::value;
     if constexpr (X3) {  // granule r = samples 2r, 2r+1: (high, low, high, low) dwords
       u32x4 eh, oh, el, ol;
 #pragma unroll
@@ -784,7 +790,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_wgrad(WgArgs a) {  // (2 waves p
         ol[r] = __builtin_amdgcn_perm(g[r][3], g[r][1], 0x07060302u);
       }
       ev.hi = __builtin_bit_cast(s16x8, eh); od.hi = __builtin_bit_cast(s16x8, oh);
-      ev.lo = __builtin_bit_cast(s16x8, unscale_lo<F16>(el)); od.lo = __builtin_bit_cast(s16x8, unscale_lo<F16>(ol));
+      ev.lo = __builtin_bit_cast(s16x8, unscale_lo<kUnscale>(el)); od.lo = __builtin_bit_cast(s16x8, unscale_lo<kUnscale>(ol));
     } else {
       unzip_rows(g[0], g[1], ev.hi, od.hi);
       ev.lo = ev.hi; od.lo = od.hi;
@@ -807,19 +813,23 @@ __global__ __launch_bounds__(64 * NW, 2) void k_wgrad(WgArgs a) {  // (2 waves p
           if (X3) {
             acc[ti][bt] = mfma32<F16>(af[ti].lo, bfr[bt].hi, acc[ti][bt]);
 #ifndef FSN_WGRAD_NOBLO  // experiment: drop the (dPre high) x (input low) product
-            acc[ti][bt] = mfma32<F16>(af[ti].hi, bfr[bt].lo, acc[ti][bt]);
+            acc[ti][bt] = mfma32<F16>(F16 ? ahs[ti] : af[ti].hi, bfr[bt].lo, acc[ti][bt]);
 #endif
           }
         }
     }
   };
   auto unzip = [&](auto ACT) {
-    unzip_section(rawA, af[0], af[1]);
+    unzip_section(rawA, af[0], af[1], std::true_type{});
+    if constexpr (F16 && X3) {
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti) ahs[ti] = __builtin_bit_cast(s16x8, unscale_lo<true>(__builtin_bit_cast(u32x4, af[ti].hi)));
+    }
     if constexpr (decltype(ACT)::value) {
 #pragma unroll
       for (int jj = 0; jj < NBP; ++jj) {
         Frag ev, od;
-        unzip_section(rawB[jj], ev, od);
+        unzip_section(rawB[jj], ev, od, std::false_type{});
         if constexpr (BT == 1) {  // one tile per wave: the even or the odd rows of the block it shares with its neighbour
           const bool odd = g0 & 1;
           bfr[0].hi = odd ? od.hi : ev.hi;

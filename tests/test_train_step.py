@@ -766,3 +766,39 @@ def test_backward_stage_scales_adapt_and_an_overflowing_stage_is_a_skipped_step(
     assert m.precision == "fp16x3" and m.grad_overflow_looks >= 1
     for a, b in zip(g1, g):
         assert float((a - b).abs().max()) <= 2e-4 * float(a.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("s", [3e-4, 1e-2, 1e2])
+def test_nerf_gradients_over_the_activation_envelope(s):
+    """The forward's float32-grade envelope (hidden activations s x the default network's, s = 3e-4 .. 1e2: layer maxima
+    from ~1e-3 to ~1e3) holds for the GRADIENTS too: every parameter gradient within 2e-4 of the tensor's largest
+    entry against float64 autograd.  (The weight-gradient GEMM keeps the activations' low parts scaled and moves the
+    2^-11 to the gradient operand; the dgrad chain scales every stage by its own power of two.)"""
+    from fs_nerf_amd.core.models import NeRF
+    from test_parity_fp64 import scaled_sd, cfg_of
+    import warnings
+    dev = torch.device("cuda:0")
+    L, D, N = 8, 256, 777
+    sd = scaled_sd(L, D, 42, s)
+    m = NeRF(3, 3, L, D, (4,), pos_fn={"n_freqs": 10, "log_space": True}, dir_fn={"n_freqs": 4, "log_space": True})
+    m.load_state_dict(sd)
+    m = m.to(dev).train()
+    gen = torch.Generator().manual_seed(1)
+    x = torch.rand(16 * N, 3, generator=gen) * 2 - 1
+    d = torch.nn.functional.normalize(torch.randn(16 * N, 3, generator=gen), dim=-1)
+    keep = _relu_margin(sd, x, d, L, [4], 10, 4) > 2e-5 * s  # (every hidden pre-activation scales by s)
+    x, d = x[keep][:N].contiguous(), d[keep][:N].contiguous()
+    assert x.shape[0] == N
+    c = torch.randn(N, 4, generator=gen)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        out = m(x.to(dev), d.to(dev))
+        (out * c.to(dev)).sum().backward()
+    assert m.precision == "fp16x3"
+    sdr = {k: v.detach().double().clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.nerf_forward(sdr, x.double(), d.double(), **cfg_of(L))
+    (ref * c.double()).sum().backward()
+    for name, p in m.named_parameters():
+        err = _rel(p.grad, sdr[name].grad)
+        assert err < 2e-4, (s, name, err)
