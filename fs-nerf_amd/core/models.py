@@ -116,6 +116,7 @@ class _NerfTrainFn(torch.autograd.Function):
             model._train_status(d_out.device).bitwise_or_(ctx.word)
             model._train_calls += 1
             if model.range_check and model._train_calls % model.range_check_every == 0:
+                model._guard_weights("training steps")
                 bits = model._read_train_status(d_out.device)
                 if bits:
                     model.fall_back("training steps (an overflowing step's gradients were zeroed on the device and its "
@@ -157,6 +158,8 @@ class NeRF(nn.Module):
         self.range_check = True
         self.range_check_every = 16  # ... in training: every that many steps (gradients are guarded on the device)
         self._train_calls = 0
+        self._pack_calls = 0
+        self.weight_check = True     # fp16 modes: look at the layers' largest weights when (re-)packing (_guard_weights)
         self._train_word: Optional[Tensor] = None
         self._bwd_stage = None       # (scales, maxima) of the backward's delayed per-stage gradient scaling (fp16 modes)
         self._bwd_calibrated = False
@@ -229,11 +232,32 @@ class NeRF(nn.Module):
         mods = list(self.layers) + [self.sigma, self.connection, self.branch, self.rgb]
         return [m.weight for m in mods], [m.bias for m in mods]
 
+    def _weights_below_envelope(self) -> bool:
+        """fp16 modes: True when some layer's LARGEST weight is below 2^-20.  High parts under 2^-14 are fp16 subnormals
+        and the scaled low parts resolve 2^-35: a layer whose largest weight is M keeps 2^-35 / M relative to it -
+        2^-18 at the 6e-6 the envelope tests run (fine against the 1e-4 bar), 2^-15 at 2^-20, where this check draws the
+        line.  (The kernels' low-end guard looks at activations; tiny weights under large activations would pass it.)
+        One small reduction per layer and one 4-byte read-back: on the first pack and every `range_check_every`-th
+        re-pack / training call."""
+        mods = list(self.layers) + [self.connection, self.branch]  # (the sigma / rgb heads are float32 dot products)
+        with torch.no_grad():
+            m = torch.stack([mod.weight.detach().abs().amax() for mod in mods])
+            return bool(((m > 0) & (m < 2.0 ** -20)).any())
+
+    def _guard_weights(self, what: str) -> None:
+        if self.range_check and self.weight_check and self.fp16_family(self.PRECISIONS[self.precision]) and \
+                self._weights_below_envelope():
+            self.fall_back(what + " (a layer's largest weight is below 2^-20)", L.FSN_STATUS_FP16_SMALL)
+
     def packed(self) -> ops.PackedMLP:
         """Weights in the MFMA streaming layout; re-packed when any parameter changed."""
         ws, bs = self._tensors()
         key = (self.precision, ws[0].device) + tuple((t.data_ptr(), t._version) for t in ws + bs)
         if self._packed is None or key != self._packed_key:
+            if self._pack_calls % max(1, int(self.range_check_every)) == 0:
+                self._guard_weights("NeRF.packed")
+                key = (self.precision,) + key[1:]
+            self._pack_calls += 1
             desc = ops.make_desc(self.n_layers, self.d_hidden, self.skip, self.pos_encoder.freqs,
                                  self.dir_encoder.freqs)
             if self._packed is None or self._packed.prec != self.PRECISIONS[self.precision] \

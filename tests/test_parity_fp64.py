@@ -375,6 +375,7 @@ def test_deferred_range_check_does_not_wait_per_call_and_is_never_silent(dev):
     def models(scale):
         mc, mf = hip_model(scaled_sd(L, D, 42, scale), L, D, dev, "fp16x3"), hip_model(scaled_sd(L, D, 43, scale), L, D, dev, "fp16x3")
         mc.range_check = mf.range_check = "deferred"
+        mc.weight_check = mf.weight_check = False  # (scaled_sd's 1/s on the connection weights is not what is tested here)
         return mc, mf
 
     render = lambda mc, mf: Rm.render_rays(o, d, est, mc, white_bkgd=True, device=dev, model_fine=mf, u=u.to(dev), u_fine=uf.to(dev))
@@ -642,3 +643,29 @@ def test_two_phase_and_camera_modes_are_bitwise_the_plain_launch(dev):
                            n_importance=128, bkgd=(1.0, 1.0, 1.0), want_extras=True)
     for k in ("weights", "edges", "weights_coarse", "rgbs"):
         assert torch.equal(ex[3][k], ex1[3][k]), k
+
+
+@pytest.mark.gpu
+def test_weights_below_the_fp16_envelope_are_reported(dev):
+    """A layer whose LARGEST weight is below 2^-20 (high parts deep in fp16's subnormals: fewer than 15 bits relative to
+    the layer's weights): the weights' own check at pack time reports it - bf16x3 with a warning, never silently."""
+    sd = make_sd(8, 256, 42)
+    sd["layers.2.weight"] = sd["layers.2.weight"] * 1e-5   # largest entry ~6e-7
+    sd["layers.2.bias"] = sd["layers.2.bias"] * 1e-5
+    sd["layers.3.weight"] = sd["layers.3.weight"] * 1e5    # the next layer brings the scale back
+    m = hip_model(sd, 8, 256, dev, "fp16x3")
+    x = torch.rand(500, 3) * 2 - 1
+    d = torch.nn.functional.normalize(torch.randn(500, 3), dim=-1)
+    with pytest.warns(RuntimeWarning, match="largest weight is below"):
+        with torch.no_grad():
+            y = m(x.to(dev), d.to(dev))
+    assert m.precision == "bf16x3"
+    want = O.nerf_forward({k: v.double() for k, v in sd.items()}, x.double(), d.double(), **cfg_of(8))
+    assert float((y.cpu().double() - want).abs().max()) < 2e-3 * max(1.0, float(want.abs().max()))
+    ok = hip_model(make_sd(8, 256, 42), 8, 256, dev, "fp16x3")
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        with torch.no_grad():
+            ok(x.to(dev), d.to(dev))
+    assert ok.precision == "fp16x3"

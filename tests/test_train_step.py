@@ -574,6 +574,7 @@ def _guard_nets(dev, scale_bad=4e5):
         m = NeRF(3, 3, L, D, (4,), precision=prec, pos_fn={"n_freqs": 10, "log_space": True},
                  dir_fn={"n_freqs": 4, "log_space": True})
         m.load_state_dict(sd)
+        m.weight_check = False  # (scaled_sd's 1/s on the connection weights is not what these tests are about)
         return m.to(dev).train()
     return mk, scaled_sd(L, D, 43, scale_bad), scaled_sd(L, D, 42, 1.0)
 
