@@ -172,3 +172,79 @@ def test_update_and_render_through_reference_call_shape():
 
     wc, wo, wd, _ = O.rendering_packed(t0, t1, ric, 256, fn, torch.ones(3))
     assert float((rgb.cpu() - wc).abs().max()) < 2e-4 and float((opacity.cpu() - wo).abs().max()) < 2e-4
+
+
+def _relu_margin_rel(sd, x, d, L, skip):
+    """per sample: min over the ReLU layers of (smallest |pre-activation| / the layer's largest over the batch), float64"""
+    sd = {k: v.double() for k, v in sd.items()}
+    pe = O.posenc(x.double(), 10, True)
+    h, margin = pe, torch.full((x.shape[0],), 1e9, dtype=torch.float64)
+    for i in range(L):
+        z = torch.nn.functional.linear(h, sd[f"layers.{i}.weight"], sd[f"layers.{i}.bias"])
+        margin = torch.minimum(margin, z.abs().amin(dim=1) / z.abs().max())
+        h = torch.relu(z)
+        if i in skip:
+            h = torch.cat([h, pe], dim=-1)
+    f = torch.nn.functional.linear(h, sd["connection.weight"], sd["connection.bias"])
+    zb = torch.nn.functional.linear(torch.cat([f, O.posenc(d.double(), 4, True)], dim=-1), sd["branch.weight"], sd["branch.bias"])
+    return torch.minimum(margin, zb.abs().amin(dim=1) / zb.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("net", [(4, 128, ()), (8, 256, (4,))])
+def test_training_step_gradients_through_the_occupancy_path(net):
+    """The reference's training call shape (run-nerf.py:243-285: render_rays with the occupancy estimator, train=True,
+    loss.backward()): parameter gradients of the packed, variable-length path (ray-form forward on the kept samples,
+    fsn_composite_packed_bwd, the MFMA backward) within 2e-4 of the tensor's largest entry against float64 autograd on
+    the oracle evaluated on the same samples.  Rays holding a sample with a ReLU unit within 4e-6 (relative) of zero get
+    zero weight in the loss of BOTH computations: such a unit takes the other branch in one of them, which is not what
+    is measured here (float32 autograd deviates from float64 autograd by 3e-4 on this batch for that reason)."""
+    from fs_nerf_amd.core.models import NeRF
+    from fs_nerf_amd.core.optim import FusedAdam
+    from fs_nerf_amd.render import rendering as Rm
+    from fs_nerf_amd.render.occgrid import OccGridEstimator
+    dev = torch.device("cuda:0")
+    L, D, skip = net
+    sd = O.init_nerf_state_dict(L, D, list(skip), 10, 4, seed=6)
+    sd["sigma.weight"] *= 16.0
+    sd["sigma.bias"] += 1.0
+    m = NeRF(3, 3, L, D, skip, pos_fn={"n_freqs": 10, "log_space": True}, dir_fn={"n_freqs": 4, "log_space": True})
+    m.load_state_dict(sd)
+    m = m.to(dev).train()
+    opt = FusedAdam(m.parameters(), lr=1e-3)  # gradients land in the flat bucket (the accumulate path of the backward)
+    est = OccGridEstimator(roi_aabb=torch.tensor(AABB), resolution=32, levels=1).to(dev)
+    est.set_binaries(_sphere_binaries(32, 1))
+    est.train()
+    R, step = 800, 2e-2
+    o, d = _orbit_rays(R, 3)
+    # pass 1 (no gradients): which samples the step will see (the jitter comes from the estimator's generator)
+    est.generator = torch.Generator(device=dev).manual_seed(2)
+    with torch.no_grad():
+        _, ri0, tv0 = Rm.render_rays(o, d, est, m, train=True, white_bkgd=True, render_step_size=step, device=dev)
+    ri0, tv0 = ri0.cpu(), tv0.cpu()
+    risky = _relu_margin_rel(sd, o[ri0] + d[ri0] * tv0[:, None], d[ri0], L, skip) < 4e-6
+    ray_ok = torch.ones(R, dtype=torch.bool)
+    ray_ok[ri0[risky]] = False
+    assert int(ray_ok.sum()) >= 40, int(ray_ok.sum())
+    c = torch.randn(R, 3, generator=torch.Generator().manual_seed(4)) * ray_ok[:, None]
+    # pass 2: the training step
+    est.generator = torch.Generator(device=dev).manual_seed(2)
+    opt.zero_grad()
+    (rgb, _, _, _), ri, tv = Rm.render_rays(o, d, est, m, train=True, white_bkgd=True, render_step_size=step, device=dev)
+    assert torch.equal(ri.cpu(), ri0) and torch.equal(tv.cpu(), tv0) and ri.numel() > 2000 and rgb.requires_grad
+    (rgb * c.to(dev)).sum().backward()
+    cfg = dict(n_layers=L, skip=list(skip), n_freqs=10, n_freqs_dir=4)
+    sdr = {k: v.detach().double().clone().requires_grad_(True) for k, v in sd.items()}
+    oo, dd = o.double(), d.double()
+    t0, t1 = (tv0 - step / 2).double(), (tv0 + step / 2).double()
+
+    def fn(a, b, cc):
+        y = O.nerf_forward(sdr, oo[cc] + dd[cc] * ((a + b) / 2)[:, None], dd[cc], **cfg)
+        return y[:, :3], y[:, 3]
+
+    col = O.rendering_packed(t0, t1, ri0, R, fn, torch.ones(3, dtype=torch.float64))[0]
+    (col * c.double()).sum().backward()
+    for name, p in m.named_parameters():
+        t = sdr[name].grad
+        err = float((p.grad.cpu().double() - t).abs().max() / t.abs().max().clamp(min=1e-30))
+        assert err < 2e-4, (name, err)
