@@ -23,6 +23,9 @@ def test_every_declared_symbol_is_exported_and_bound():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.fsn_version() >= 100
+    # the #define constants of the header and their Python mirrors
+    for name, val in re.findall(r"#define\s+(FSN_(?:STATUS|PREC)_[A-Z0-9_]+)\s+(\d+)u?", hdr):
+        assert getattr(L, name) == int(val), name
 
 
 def test_argument_validation_without_gpu():
