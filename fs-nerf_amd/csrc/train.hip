@@ -160,10 +160,12 @@ __global__ void k_grad_scale(const float* __restrict__ x, int64_t n, float* __re
     mx = o > mx ? o : mx;
   }
   uint32_t* w = reinterpret_cast<uint32_t*>(buf);
-  __shared__ uint32_t last;
-  if ((threadIdx.x & 63) == 0) atomicMax(w + 1, mx);
+  __shared__ uint32_t last, wmax[4];
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0) {  // ONE atomic per workgroup (thousands of them on one address serialise: the launch took 50 us)
+    const uint32_t a01 = wmax[0] > wmax[1] ? wmax[0] : wmax[1], a23 = wmax[2] > wmax[3] ? wmax[2] : wmax[3];
+    atomicMax(w + 1, a01 > a23 ? a01 : a23);
     __threadfence();
     last = atomicAdd(w + 2, 1u) == gridDim.x - 1 ? 1u : 0u;
   }
@@ -181,7 +183,7 @@ __global__ void k_grad_scale(const float* __restrict__ x, int64_t n, float* __re
 extern "C" int fsn_grad_scale(const float* d_out, int64_t n, float* buf, fsn_stream_t stream) {
   FSN_REQUIRE(n >= 0 && buf && (n == 0 || d_out), FSN_E_INVALID, "fsn_grad_scale: bad arguments");
   int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
-  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+  blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
   k_grad_scale<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(d_out, n, buf);
   FSN_LAUNCH_CHECK("k_grad_scale");
   return FSN_OK;
