@@ -254,6 +254,19 @@ __global__ __launch_bounds__(kThreads) void k_render_occ(OccKArgs k) {
       }
     }
     lds_barrier();
+    if (a.sample_t0) {  // sampler mode: the kept samples are the result
+      for (int r = wave; r < n_rays; r += kWaves) {
+        const int64_t ray = S.ray_id[r];
+        const int ko = S.kept_off[r], Sk = S.kept_cnt[r];
+        for (int i = lane; i < Sk; i += 64) a.sample_t0[ray * a.sample_cap + i] = S.t0k[ko + i];
+        if (lane == 0) {
+          if (a.n_cand) a.n_cand[ray] = S.cand_cnt[r];
+          a.n_kept[ray] = Sk;
+        }
+      }
+      lds_barrier();
+      continue;
+    }
     // ------------------------------------------------------------ full pass (rgb_sigma_fn) + packed integration
     const int n_kept = S.n_kept;
     for (int sub = 0; sub * 128 < n_kept; ++sub) {
@@ -313,8 +326,13 @@ extern "C" int fsn_render_rays_occgrid(const fsn_mlp_desc* desc, int prec, const
   rc = make_grid(a.aabb, a.res, a.levels, k.G);
   if (rc != FSN_OK) return rc;
   if (a.R == 0) return FSN_OK;
-  FSN_REQUIRE(blob && a.bits && a.colors && a.opacity && a.depth && a.work_counter, FSN_E_INVALID,
-              "fsn_render_rays_occgrid: null pointer");
+  FSN_REQUIRE(blob && a.bits && a.work_counter, FSN_E_INVALID, "fsn_render_rays_occgrid: null pointer");
+  if (a.sample_t0) {
+    FSN_REQUIRE(a.n_kept && a.sample_cap >= a.max_steps, FSN_E_INVALID,
+                "fsn_render_rays_occgrid: the sampler mode needs n_kept and sample_cap >= max_steps");
+  } else {
+    FSN_REQUIRE(a.colors && a.opacity && a.depth, FSN_E_INVALID, "fsn_render_rays_occgrid: null output pointer");
+  }
   FSN_REQUIRE(a.max_steps <= kCap, FSN_E_UNSUPPORTED,
               "fsn_render_rays_occgrid: max_steps %d > %d samples of one ray group (use the unfused path)", a.max_steps, kCap);
   if (a.rays_o) {
@@ -353,4 +371,35 @@ extern "C" int fsn_render_rays_occgrid(const fsn_mlp_desc* desc, int prec, const
     case 6: return launch_occ<8, 2>(k, cus, s);
     default: return launch_occ<8, 3>(k, cus, s);
   }
+}
+
+namespace fsn {
+__global__ void k_occ_gather(const int32_t* __restrict__ n_kept, const int64_t* __restrict__ offsets,
+                             const float* __restrict__ t0s, int cap, int64_t R, float step, int64_t* __restrict__ ri,
+                             float* __restrict__ ts, float* __restrict__ te) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+  if (r >= R) return;
+  const int n = n_kept[r];
+  const int64_t off = offsets[r];
+  for (int i = lane; i < n; i += 64) {
+    const float t = t0s[r * cap + i];
+    ri[off + i] = r;
+    ts[off + i] = t;
+    te[off + i] = t + step;
+  }
+}
+}  // namespace fsn
+
+extern "C" int fsn_occ_gather_samples(const int32_t* n_kept, const int64_t* offsets, const float* sample_t0, int sample_cap,
+                                      int64_t R, float step, int64_t* ray_indices, float* t_starts, float* t_ends,
+                                      fsn_stream_t stream) {
+  FSN_REQUIRE(R >= 0 && sample_cap > 0, FSN_E_INVALID, "fsn_occ_gather_samples: bad sizes");
+  if (R == 0) return FSN_OK;
+  FSN_REQUIRE(n_kept && offsets && sample_t0 && ray_indices && t_starts && t_ends, FSN_E_INVALID,
+              "fsn_occ_gather_samples: null pointer");
+  k_occ_gather<<<(unsigned)((R + 3) / 4), 256, 0, as_stream(stream)>>>(n_kept, offsets, sample_t0, sample_cap, R, step,
+                                                                       ray_indices, t_starts, t_ends);
+  FSN_LAUNCH_CHECK("k_occ_gather");
+  return FSN_OK;
 }

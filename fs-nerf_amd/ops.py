@@ -710,6 +710,60 @@ def occgrid_march(rays_o: Tensor, rays_d: Tensor, aabb: Sequence[float], res: in
 _work_counters: Dict[torch.device, Tensor] = {}
 
 
+def occ_sample_fused(pm: PackedMLP, rays_o: Tensor, rays_d: Tensor, *, aabb: Sequence[float], res: int, levels: int, bits: Tensor,
+                     near_plane: float, far_plane: float, step: float, max_steps: int, u: Optional[Tensor] = None,
+                     early_stop_eps: float = 1e-4, alpha_thre: float = 0.0, pos_mask: Optional[Tensor] = None,
+                     dir_mask: Optional[Tensor] = None, status: Optional[Tensor] = None):
+    """OccGridEstimator.sampling(..., sigma_fn = the model's density) of a training step as ONE launch + one gather:
+    grid march -> density pass -> visibility cull inside persistent workgroups (the sampler mode of
+    fsn_render_rays_occgrid), the kept samples of every ray in a slot of its own, then an exclusive scan of the counts,
+    ONE host read (the sample count sizes the outputs) and fsn_occ_gather_samples.  -> (ray_indices int64 [N], t_starts
+    [N], t_ends [N]): what occgrid_march (two launches + a read) -> density pass -> packed_visibility -> compaction
+    (a second read) give, bit for bit."""
+    o, d = _f32(rays_o, "rays_o").reshape(-1, 3), _f32(rays_d, "rays_d").reshape(-1, 3)
+    Rn, dev = o.shape[0], o.device
+    a = L.OccRenderArgs()
+    a.R, a.rays_o, a.rays_d = Rn, o.data_ptr(), d.data_ptr()
+    keep = [o, d]
+    for i in range(6):
+        a.aabb[i] = float(aabb[i])
+    a.res, a.levels, a.bits = int(res), int(levels), bits.data_ptr()
+    a.near_plane, a.far_plane, a.step, a.max_steps = float(near_plane), float(far_plane), float(step), int(max_steps)
+    if u is not None:
+        u = _f32(u, "u").reshape(-1)
+        if u.numel() != Rn:
+            raise ValueError("u must hold one value per ray")
+        keep.append(u)
+        a.u = u.data_ptr()
+    a.early_stop_eps, a.alpha_thre = float(early_stop_eps), float(alpha_thre)
+    for name, m in (("pos_mask", pos_mask), ("dir_mask", dir_mask)):
+        if m is not None:
+            m = _f32(m, name)
+            keep.append(m)
+            setattr(a, name, m.data_ptr())
+    n_kept = torch.zeros(Rn, dtype=torch.int32, device=dev)
+    slots = torch.empty(max(Rn, 1), int(max_steps), dtype=torch.float32, device=dev)
+    a.n_kept, a.sample_t0, a.sample_cap = n_kept.data_ptr(), slots.data_ptr(), int(max_steps)
+    wc = _work_counters.get(dev)
+    if wc is None:
+        wc = _work_counters[dev] = torch.zeros(1, dtype=torch.int64, device=dev)
+    a.work_counter = wc.data_ptr()
+    a.status = (status_word(dev) if status is None else status).data_ptr()
+    with torch.cuda.device(dev):
+        if Rn > 0:
+            L.check(L.lib().fsn_render_rays_occgrid(C.byref(pm.desc), pm.prec, _p(pm.blob), C.byref(a), _stream()),
+                    "fsn_render_rays_occgrid (sampler mode)")
+        incl = torch.cumsum(n_kept, 0, dtype=torch.int64)
+        N = int(incl[-1].item()) if Rn > 0 else 0  # the one host read: the sample count sizes the outputs
+        ri = torch.empty(N, dtype=torch.int64, device=dev)
+        ts, te = torch.empty(N, device=dev), torch.empty(N, device=dev)
+        if N > 0:
+            offs = incl - n_kept
+            L.check(L.lib().fsn_occ_gather_samples(_p(n_kept), _p(offs), _p(slots), int(max_steps), Rn, float(step), _p(ri),
+                                                   _p(ts), _p(te), _stream()), "fsn_occ_gather_samples")
+    return ri, ts, te
+
+
 def render_occ_fused(pm: PackedMLP, rays_o: Optional[Tensor], rays_d: Optional[Tensor], *, aabb: Sequence[float], res: int,
                      levels: int, bits: Tensor, near_plane: float, far_plane: float, step: float, max_steps: int,
                      u: Optional[Tensor] = None, early_stop_eps: float = 1e-4, alpha_thre: float = 0.0,

@@ -170,6 +170,16 @@ def _fused_launch(rays_o, rays_d, camera, estimator, model, model_fine, train, b
     return out
 
 
+# render_rays with gradients / extras: OccGridEstimator.sampling as one launch + one gather (ops.occ_sample_fused), for
+# calls with at least this many rays.  Measured on the reference's training step (4096 rays, 353 marched samples per ray):
+# SLOWER than the unfused sequence, 7.8-8.1 against 6.8-7.2 ms per step - the launch hands out rays in chunks of eight
+# from a work queue, 4096 rays are two chunks per workgroup, and a workgroup that draws two dense chunks marches and
+# evaluates 9,000 candidates while its neighbour has none; the standalone density pass balances 128-sample tiles over
+# the chip.  Frames (640,000 rays) are where the fused launch wins (655 against 719 ms).
+FUSED_OCC_SAMPLER = True
+FUSED_OCC_SAMPLER_MIN_RAYS = 32768
+
+
 def _occ_fusable(estimator, model, model_fine, render_step_size: float) -> bool:
     return isinstance(estimator, OccGridEstimator) and isinstance(model, NeRF) and model_fine is None and \
         model.precision in ("fp16x3", "bf16x3", "fp16", "bf16") and estimator.max_steps(render_step_size) <= FUSED_OCC_MAX_STEPS
@@ -282,6 +292,30 @@ def render_rays(rays_o: Tensor, rays_d: Tensor, estimator, model: nn.Module, tra
                         model.fall_back("the sampler's density pass", bits)
                         edges = ops.sample_fused(model.packed(), rays_o, rays_d, **kw_s)
                 ray_indices, t_starts, t_ends = ops.edges_to_packed(edges)
+        elif FUSED_OCC_SAMPLER and rays_o.shape[0] >= max(1, FUSED_OCC_SAMPLER_MIN_RAYS) and \
+                _occ_fusable(estimator, model, None, render_step_size):
+            # estimator.sampling(..., sigma_fn) of the reference's training step (rendering.py:66-74) as one launch + one
+            # gather (ops.occ_sample_fused): the same samples bit for bit as march -> density pass -> visibility ->
+            # compaction, one host read instead of two.  Range guard as for the stratified sampler above.
+            dev_ = rays_o.device
+            uu = torch.rand(rays_o.shape[0], device=dev_, generator=estimator.generator) if train else None
+            kw_o = dict(aabb=estimator.aabb, res=estimator.resolution, levels=estimator.levels, bits=estimator.bits,
+                        near_plane=0.0, far_plane=1e10, step=render_step_size, max_steps=estimator.max_steps(render_step_size),
+                        u=uu, early_stop_eps=1e-4, alpha_thre=0.0, pos_mask=model._mask(model.pos_mask, dev_),
+                        dir_mask=model._mask(model.dir_mask, dev_))
+            f16 = model.fp16_family(model.PRECISIONS[model.precision])
+            with torch.no_grad():
+                if needs_grad and f16 and model.range_check:
+                    word = torch.zeros(1, dtype=torch.int32, device=dev_)
+                    ray_indices, t_starts, t_ends = ops.occ_sample_fused(model.packed(), rays_o, rays_d, status=word, **kw_o)
+                    ops.step_flag(dev_).bitwise_or_(word)
+                    model._train_status(dev_).bitwise_or_(word)
+                else:
+                    ray_indices, t_starts, t_ends = ops.occ_sample_fused(model.packed(), rays_o, rays_d, **kw_o)
+                    bits = ops.range_flags(dev_) if model.range_check is True and f16 else 0
+                    if bits:
+                        model.fall_back("the sampler's density pass", bits)
+                        ray_indices, t_starts, t_ends = ops.occ_sample_fused(model.packed(), rays_o, rays_d, **kw_o)
         else:
             ray_indices, t_starts, t_ends = estimator.sampling(
                 rays_o, rays_d, sigma_fn=sigma_fn, render_step_size=render_step_size, stratified=train,

@@ -246,10 +246,22 @@ typedef struct fsn_occ_render_args {
   float cam_pose[12];
   int32_t cam_H, cam_W, cam_row0;
   double cam_focal;
+  /* SAMPLER mode (sample_t0 != NULL; estimator.sampling(..., sigma_fn) of a training step, rendering.py:58-74): every
+   * batch stops after the visibility cull; per ray the kept count goes to n_kept (required) and the kept samples'
+   * interval starts to sample_t0[ray * sample_cap + i] (sample_cap >= max_steps); colors / opacity / depth are not
+   * written and may be NULL.  fsn_occ_gather_samples packs the slots behind an exclusive scan of n_kept. */
+  float* sample_t0;
+  int32_t sample_cap;
 } fsn_occ_render_args;
 
 int fsn_render_rays_occgrid(const fsn_mlp_desc* desc, int prec, const void* blob, const fsn_occ_render_args* args_host,
                             fsn_stream_t stream);
+/* Packed (ray_indices, t_starts, t_ends = t_start + step) from the sampler mode's per-ray slots: offsets = exclusive
+ * scan of n_kept (int64 [R]); the outputs hold sum(n_kept) entries, sorted by ray then t - what fsn_occgrid_march +
+ * fsn_packed_visibility + a compaction produce, bit for bit. */
+int fsn_occ_gather_samples(const int32_t* n_kept, const int64_t* offsets, const float* sample_t0, int sample_cap,
+                           int64_t R, float step, int64_t* ray_indices, float* t_starts, float* t_ends,
+                           fsn_stream_t stream);
 
 /* ---- "next" rows ------------------------------------------------------------------ */
 

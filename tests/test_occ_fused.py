@@ -155,3 +155,43 @@ def test_fused_occupancy_frame_is_one_launch_and_matches_the_ray_path(dev):
     assert torch.equal(img.reshape(-1, 3), rgb_f) and torch.equal(rgb_f, rgb_u)
     assert torch.equal(depth.reshape(-1), dep_u.reshape(-1).clamp(2.0, 6.0))
     assert 0.05 < float((torch.bincount(ri, minlength=o.shape[0]) > 0).float().mean()) < 0.95, "part of the frame is empty space"
+
+
+@pytest.mark.parametrize("net,res,levels,step,train", [((4, 128), 32, 1, 2e-2, True), ((8, 256), 64, 2, 1e-2, True),
+                                                        ((8, 256), 32, 1, 2e-2, False)])
+def test_fused_occupancy_sampler_is_the_unfused_sampling(dev, net, res, levels, step, train):
+    """ops.occ_sample_fused (sampler mode of the fused launch + gather: what render_rays uses for estimator.sampling
+    when the step needs gradients or extras) == OccGridEstimator.sampling(..., sigma_fn) - march, density pass,
+    visibility cull, compaction - bit for bit: ray_indices, t_starts, t_ends; rays without samples, ragged ends."""
+    from fs_nerf_amd import ops
+    from fs_nerf_amd.render import rendering as Rm
+    m = make_model(net[0], net[1], 4, dev)
+    est = sphere_grid(res, levels, dev)
+    if train:
+        est.train()
+    o, d = orbit_rays(1003, 5)
+    miss = torch.arange(o.shape[0]) % 5 == 0
+    d = d.clone()
+    d[miss] = -d[miss]
+    od, dd = o.to(dev), d.to(dev)
+    u = torch.rand(o.shape[0], device=dev, generator=torch.Generator(device=dev).manual_seed(77)) if train else None
+    with torch.no_grad():
+        ri_u, ts_u, te_u = est.sampling(od, dd, sigma_fn=lambda a, b, c: m.forward_rays(od, dd, c, a, b, full=False).squeeze(-1),
+                                        render_step_size=step, u=u)
+        ri_f, ts_f, te_f = ops.occ_sample_fused(m.packed(), od, dd, aabb=est.aabb, res=est.resolution, levels=est.levels,
+                                                bits=est.bits, near_plane=0.0, far_plane=1e10, step=step,
+                                                max_steps=est.max_steps(step), u=u)
+    assert ri_u.numel() > 500 and int(torch.bincount(ri_u, minlength=o.shape[0])[miss.to(dev)].max()) == 0
+    assert torch.equal(ri_f, ri_u) and torch.equal(ts_f, ts_u) and torch.equal(te_f, te_u)
+    # and through render_rays: the training call takes the fused sampler, FUSED_OCC_SAMPLER = False the unfused one
+    m.train()
+    outs = []
+    floor = Rm.FUSED_OCC_SAMPLER_MIN_RAYS
+    Rm.FUSED_OCC_SAMPLER_MIN_RAYS = 0  # (by default only calls with >= 32768 rays take the fused sampler)
+    for flag in (True, False):
+        Rm.FUSED_OCC_SAMPLER = flag
+        est.generator = torch.Generator(device=dev).manual_seed(9)
+        (rgb, _, _, _), ri, tv = Rm.render_rays(o, d, est, m, train=train, white_bkgd=True, render_step_size=step, device=dev)
+        outs.append((rgb.detach(), ri, tv))
+    Rm.FUSED_OCC_SAMPLER, Rm.FUSED_OCC_SAMPLER_MIN_RAYS = True, floor
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][0], outs[1][0])
