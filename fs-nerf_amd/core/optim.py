@@ -12,7 +12,11 @@ Differences from `torch.optim.Adam`, all deliberate:
   * `zero_grad(set_to_none=True)` fills the gradient arena with zeros and keeps `p.grad` bound to it;
   * a step in which an fp16-mode training launch overflowed is skipped on the device (`ops.step_flag`, or the flag
     slot of an all-reduced bucket): parameters and moments untouched; the host-side step counter still advances, so
-    the bias corrections run one step ahead per skipped step (the model leaves fp16 mode right after);
+    the bias corrections run one step ahead per skipped step (overflowing ACTIVATIONS: the model leaves fp16 mode at
+    the host's next look; an overflowing GRADIENT under the backward's delayed per-stage scaling: the stage's factor
+    drops and training continues in the same mode, like a loss scaler's skipped step);
+  * the backward kernels add into the gradient arena's views directly (`fsn_nerf_train_bwd(accumulate=1)`): autograd
+    sees no gradient tensors for those parameters (parameter hooks do not fire; use `loss.backward()`);
   * `state_dict()` / `load_state_dict()` carry the flat moments and the step count (checkpoint / resume)."""
 from typing import Iterable, List, Optional
 
