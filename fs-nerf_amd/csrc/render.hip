@@ -258,7 +258,7 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
     // one group at a time: coarse pass, resampling, fine pass, integration (the weight stream alternates between
     // the two networks; small launches, or no hand-over buffer)
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-      const int64_t r0 = grp * GRP_G;
+      const int64_t r0 = grp * (int64_t)__builtin_amdgcn_readfirstlane(GRP_G);  // (G comes from LDS: keep r0 scalar)
       load_rays(r0);
       coarse_stage(r0);
       fine_stage(r0, GRP_HIER ? S_.edgesF : S_.edgesC, true);
@@ -270,14 +270,18 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
     // same time, so the XCD's 4 MiB L2 holds one weight stream (2.0 MB coarse, then 2.3 MB fine) instead of
     // thrashing on both; the weight stream's schedule is "coarse x all tiles, then fine x all tiles" (init below).
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-      const int64_t r0 = grp * GRP_G;
+      const int64_t r0 = grp * (int64_t)__builtin_amdgcn_readfirstlane(GRP_G);  // (G comes from LDS: keep r0 scalar)
       load_rays(r0);
       coarse_stage(r0);
       for (int e = tid; e < GRP_G * (GRP_SO + 1); e += kThreads) {
         const int g = e / (GRP_SO + 1), i = e - g * (GRP_SO + 1);
         // (streaming: written once here, read once below, 494 MB per 800x800 frame - kept out of the way of the
         // weight streams the XCD's L2 is there for)
+#ifdef FSN_EDGES_PLAIN  // experiment: plain (L2 write-back) hand-over stores / loads
+        if (r0 + g < GRP_R) a.edges_out[(r0 + g) * (GRP_SO + 1) + i] = S_.edgesF[e];
+#else
         if (r0 + g < GRP_R) __builtin_nontemporal_store(S_.edgesF[e], a.edges_out + (r0 + g) * (GRP_SO + 1) + i);
+#endif
       }
       lds_barrier();
     }
@@ -293,11 +297,15 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
       return;
     }
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-      const int64_t r0 = grp * GRP_G;
+      const int64_t r0 = grp * (int64_t)__builtin_amdgcn_readfirstlane(GRP_G);  // (G comes from LDS: keep r0 scalar)
       load_rays(r0);
       for (int e = tid; e < GRP_G * (GRP_SO + 1); e += kThreads) {
         const int g = e / (GRP_SO + 1), i = e - g * (GRP_SO + 1);
+#ifdef FSN_EDGES_PLAIN
+        S_.edgesF[e] = a.edges_out[min(r0 + g, GRP_R - 1) * (GRP_SO + 1) + i];
+#else
         S_.edgesF[e] = __builtin_nontemporal_load(a.edges_out + min(r0 + g, GRP_R - 1) * (GRP_SO + 1) + i);
+#endif
       }
       lds_barrier();
       fine_stage(r0, S_.edgesF, false);
