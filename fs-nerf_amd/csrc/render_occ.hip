@@ -70,6 +70,12 @@ struct OccSrc {
   __device__ __forceinline__ void dir(float& x, float& y, float& z) const { x = ray[3]; y = ray[4]; z = ray[5]; }
 };
 
+__device__ __forceinline__ int64_t uniform_i64(int64_t v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
 // exclusive prefix sum of an int over the 64 lanes; total to all
 __device__ __forceinline__ int wave_excl_scan_i(int v, int& total) {
   const int lane = lane_id();
@@ -129,8 +135,11 @@ __global__ __launch_bounds__(kThreads) void k_render_occ(OccKArgs k) {
         }
       }
       __syncthreads();
-      const int64_t base = S.chunk_base;
-      const int from = S.chunk_from;
+      // (values read back from LDS arrive in VGPRs; these are workgroup-uniform and live across the barriers below:
+      // kept scalar, they are not spilled per lane - 8-byte spill stores per lane and batch were 2 GB of scratch
+      // writes per frame)
+      const int64_t base = uniform_i64(S.chunk_base);
+      const int from = __builtin_amdgcn_readfirstlane(S.chunk_from);
       if (base >= a.R) break;  // (workgroup-uniform: read from LDS)
       const int64_t ray = base + wave;
       const bool active = wave >= from && ray < a.R;
@@ -184,7 +193,7 @@ __global__ __launch_bounds__(kThreads) void k_render_occ(OccKArgs k) {
       __syncthreads();
       if (S.stop) break;
     }
-    const int n_rays = S.n_rays, n_cand = S.n_cand;
+    const int n_rays = __builtin_amdgcn_readfirstlane(S.n_rays), n_cand = __builtin_amdgcn_readfirstlane(S.n_cand);
     if (n_rays == 0) break;  // no ray left for this workgroup (uniform)
 
     // ------------------------------------------------------------ density pass + visibility (estimator.sampling)
@@ -268,7 +277,7 @@ __global__ __launch_bounds__(kThreads) void k_render_occ(OccKArgs k) {
       continue;
     }
     // ------------------------------------------------------------ full pass (rgb_sigma_fn) + packed integration
-    const int n_kept = S.n_kept;
+    const int n_kept = __builtin_amdgcn_readfirstlane(S.n_kept);
     for (int sub = 0; sub * 128 < n_kept; ++sub) {
       const int idx = sub * 128 + wave * 16 + (lane & 15);
       const int ic = min(idx, n_kept - 1);
