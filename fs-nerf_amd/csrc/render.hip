@@ -133,7 +133,23 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
     st.init(smem, k.netC.blob + k.netC.stream_off, GRP_HIER ? (uint32_t)k.netC.nph_density : 0u, repC,
             k.netF.blob + k.netF.stream_off, (uint32_t)k.netF.nph_full, repF);
   }
+  // The thread id is laundered once per group (an empty asm the compiler cannot see through): lane-derived LDS addresses
+  // are then RECOMPUTED per group (a few VALU instructions) instead of being hoisted to the kernel's entry, spilled
+  // around the MFMA passes and reloaded per tile - each reload a VMEM load whose compiler-inserted vmcnt(0) also drains
+  // the hand-counted LDS-DMA prefetch.  57 -> 20 spilled VGPRs, 144 -> 68 bytes of scratch per lane; fp16x3 frame
+  // unchanged (427.2 / 427.5 ms), bf16 frame 137.5 -> 134.8 ms (FSN_NO_LAUNDER_TID: the plain form).
+#ifndef FSN_NO_LAUNDER_TID
+  int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#define FSN_RELAUNDER()                                              \
+  do {                                                               \
+    int t_ = threadIdx.x;                                            \
+    asm volatile("" : "+v"(t_));                                     \
+    tid = t_; wave = __builtin_amdgcn_readfirstlane(t_ >> 6); lane = t_ & 63; \
+  } while (0)
+#else
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#define FSN_RELAUNDER() do {} while (0)
+#endif
   constexpr int NG = groups_per_wave<NT, PREC>(), TILE = 128 * NG;
   ARing ring;
   prime_ring<PREC, NT>(st, ring);
@@ -258,6 +274,7 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
     // one group at a time: coarse pass, resampling, fine pass, integration (the weight stream alternates between
     // the two networks; small launches, or no hand-over buffer)
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+      FSN_RELAUNDER();
       const int64_t r0 = grp * (int64_t)__builtin_amdgcn_readfirstlane(GRP_G);  // (G comes from LDS: keep r0 scalar)
       load_rays(r0);
       coarse_stage(r0);
@@ -270,6 +287,7 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
     // same time, so the XCD's 4 MiB L2 holds one weight stream (2.0 MB coarse, then 2.3 MB fine) instead of
     // thrashing on both; the weight stream's schedule is "coarse x all tiles, then fine x all tiles" (init below).
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+      FSN_RELAUNDER();
       const int64_t r0 = grp * (int64_t)__builtin_amdgcn_readfirstlane(GRP_G);  // (G comes from LDS: keep r0 scalar)
       load_rays(r0);
       coarse_stage(r0);
@@ -297,6 +315,7 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
       return;
     }
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+      FSN_RELAUNDER();
       const int64_t r0 = grp * (int64_t)__builtin_amdgcn_readfirstlane(GRP_G);  // (G comes from LDS: keep r0 scalar)
       load_rays(r0);
       for (int e = tid; e < GRP_G * (GRP_SO + 1); e += kThreads) {
