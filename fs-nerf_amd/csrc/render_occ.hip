@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kThreads) void k_render_occ(OccKArgs k) {
   __shared__ __attribute__((aligned(1024))) char smem[kOccLdsBytes];
   float* aux = reinterpret_cast<float*>(smem + kRingBytes);
   OccLds& S = *reinterpret_cast<OccLds*>(smem + kRingBytes + (kAuxCapFloats + 96) * 4);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;  // (laundered per batch below: render.hip)
   if (tid == 0) {
     S.a = k.a; S.G = k.G; S.cam_hw = k.cam_hw; S.cam_hh = k.cam_hh; S.cam_f = k.cam_f; S.use_vis = k.use_vis;
     S.carry_from = kWaves; S.carry_base = 0;
@@ -122,6 +122,13 @@ __global__ __launch_bounds__(kThreads) void k_render_occ(OccKArgs k) {
   };
 
   for (;;) {
+#ifndef FSN_NO_LAUNDER_TID
+    {
+      int t_ = threadIdx.x;
+      asm volatile("" : "+v"(t_));
+      tid = t_; wave = __builtin_amdgcn_readfirstlane(t_ >> 6); lane = t_ & 63;
+    }
+#endif
     // ------------------------------------------------------------ build a batch
     if (tid == 0) { S.n_cand = 0; S.n_rays = 0; S.stop = 0; }
     __syncthreads();

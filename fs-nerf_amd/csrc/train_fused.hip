@@ -216,11 +216,16 @@ __global__ __launch_bounds__(kThreads) void k_train_fwd(TrainFwdArgs a) {
   const int64_t ntiles = (a.n + kTC - 1) / kTC;
   WStream st;
   st.init(smem, nullptr, 0, 0, a.net.blob + a.net.stream_off, (uint32_t)a.net.nph_full, 1);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4;
-  const int col = wave * 16 + (lane & 15);
   ARing ring;
   prime_ring<PREC>(st, ring);
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // (thread id laundered per tile: lane-derived addresses are recomputed, not hoisted and spilled - render.hip)
+    int t_ = threadIdx.x;
+#ifndef FSN_NO_LAUNDER_TID
+    asm volatile("" : "+v"(t_));
+#endif
+    const int wave = t_ >> 6, lane = t_ & 63, g = lane >> 4;
+    const int col = wave * 16 + (lane & 15);
     const int64_t s = tile * kTC + col;
     const int64_t sc = s < a.n ? s : a.n - 1;
     if (lane < 16) {
