@@ -35,6 +35,22 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(8))) short s16x8;  // 8 raw 16-bit elements (bf16 or fp16 bits)
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+// threadIdx.x behind an empty asm (FSN_LAUNDER_ALL, a measured experiment, off): values derived from it are recomputed
+// where they are used instead of being hoisted out of the tile loops and spilled.  It takes the fused kernel to ZERO
+// spilled VGPRs in bf16 and 11 in fp16x3 - and makes the frames 8 % and 3.5 % SLOWER (141.2 against 130.5 ms, 427.2
+// against 412.8 ms): the recomputation lands inside the unit loop, and the volatile asm statements order against the
+// hand-scheduled blocks.  The per-group laundering in render.hip (57 -> 20 spills) is the part that pays.
+#ifdef FSN_LAUNDER_ALL
+__device__ __forceinline__ unsigned fsn_tidx() {
+  unsigned t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+#define FSN_TIDX (fsn_tidx())
+#else
+#define FSN_TIDX threadIdx.x
+#endif
+
 #ifndef FSN_NSLOT
 #define FSN_NSLOT 4
 #endif
@@ -147,7 +163,7 @@ struct WStream {
     // wave-uniform SALU arithmetic only (as next_stage below): the M0 base and the loader predicate are formed once
     // in init(), the end of a pass is a real branch
     const uint32_t m0v = m0_base + s_slot * kPhaseBytes;
-    const uint32_t voff = ((threadIdx.x >> 6) ^ FSN_LOADER_XOR) * (kGldsPerWave * 1024) + (threadIdx.x & 63) * 16;
+    const uint32_t voff = ((FSN_TIDX >> 6) ^ FSN_LOADER_XOR) * (kGldsPerWave * 1024) + (FSN_TIDX & 63) * 16;
     const uint64_t sbase = (uint64_t)s_ptr;
     uint32_t keep;
     if (is_loader) {
@@ -176,13 +192,13 @@ struct WStream {
                                        uint32_t nB, uint32_t rB) {
     ring = ring_;
     ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring_;
-    m0_base = __builtin_amdgcn_readfirstlane(ring_lds + ((threadIdx.x >> 6) ^ FSN_LOADER_XOR) * (kGldsPerWave * 1024));
-    is_loader = __builtin_amdgcn_readfirstlane((((threadIdx.x >> 6) ^ FSN_LOADER_XOR) < (uint32_t)kLoaders) ? 1u : 0u);
+    m0_base = __builtin_amdgcn_readfirstlane(ring_lds + ((FSN_TIDX >> 6) ^ FSN_LOADER_XOR) * (kGldsPerWave * 1024));
+    is_loader = __builtin_amdgcn_readfirstlane((((FSN_TIDX >> 6) ^ FSN_LOADER_XOR) < (uint32_t)kLoaders) ? 1u : 0u);
     ptrA = pA; nphA = nA; repA = nA ? rA : 0;
     ptrB = pB; nphB = nB; repB = nB ? rB : 0;
     s_rep = 0; s_slot = 0; c_slot = 0;
     begin_pass_(repA ? 0u : 1u);
-    c_base = n_base = ring + (threadIdx.x & 63) * 16;
+    c_base = n_base = ring + (FSN_TIDX & 63) * 16;
 #pragma unroll
     for (int i = 0; i < kLook; ++i) stage();
     if (kLead > 0) open_next();  // every pass finds its first phase already opened
@@ -198,7 +214,7 @@ struct WStream {
   // staged phase), every wave is past the phase whose slot is restaged next.
   __device__ __forceinline__ void open_next() {
 #ifdef FSN_ABL_NOSTREAM  // timing experiment: no waits, barriers or staging
-    n_base = ring + c_slot * kPhaseBytes + (threadIdx.x & 63) * 16;
+    n_base = ring + c_slot * kPhaseBytes + (FSN_TIDX & 63) * 16;
     c_slot = slot_add(c_slot, 1);
     return;
 #endif
@@ -207,7 +223,7 @@ struct WStream {
     else
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((kLook - 1) * kGldsPerWave) : "memory");
     stage();
-    n_base = ring + c_slot * kPhaseBytes + (threadIdx.x & 63) * 16;
+    n_base = ring + c_slot * kPhaseBytes + (FSN_TIDX & 63) * 16;
     c_slot = slot_add(c_slot, 1);
   }
   __device__ __forceinline__ void enter_phase() { c_base = n_base; }
@@ -229,22 +245,22 @@ struct WStream {
     }
   }
   __device__ __forceinline__ uint32_t phase_lds(uint32_t k) const {
-    return ring_lds + slot_add(slot_add(c_slot, kNSlot - 1), k) * kPhaseBytes + (threadIdx.x & 63) * 16;
+    return ring_lds + slot_add(slot_add(c_slot, kNSlot - 1), k) * kPhaseBytes + (FSN_TIDX & 63) * 16;
   }
   __device__ __forceinline__ void opened(uint32_t n) {
     c_slot = slot_add(c_slot, n);
-    n_base = ring + slot_add(c_slot, kNSlot - 1) * kPhaseBytes + (threadIdx.x & 63) * 16;
+    n_base = ring + slot_add(c_slot, kNSlot - 1) * kPhaseBytes + (FSN_TIDX & 63) * 16;
     c_base = n_base;
   }
   // ---- the one-phase lag between the two waves of a SIMD (kLag).  A "pass" is a run of MLP tiles between two
   // workgroup barriers of the caller.  Waves 4..7 join one barrier event before their first unit (they then read
   // phase p while waves 0..3 read phase p+1); waves 0..3 join one after their last so that every wave has taken
   // part in the same number of events when the pass ends.  No staging, no waits: events only.
-  static __device__ __forceinline__ bool lagging() { return kLag && (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256); }
+  static __device__ __forceinline__ bool lagging() { return kLag && (__builtin_amdgcn_readfirstlane(FSN_TIDX) >= 256); }
   __device__ __forceinline__ void pass_begin() const {
 #ifdef FSN_ABL_LAGSLEEP  // timing experiment (with the barrier-free ablation of the generator): waves 4..7 start every
     // pass FSN_ABL_LAGSLEEP x 64 cycles late, so that the two waves of a SIMD run out of step
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_sleep(FSN_ABL_LAGSLEEP);
+    if (__builtin_amdgcn_readfirstlane(FSN_TIDX) >= 256) __builtin_amdgcn_s_sleep(FSN_ABL_LAGSLEEP);
 #endif
     if (kLag && lagging()) asm volatile("s_barrier" ::: "memory");
   }
@@ -394,7 +410,7 @@ __device__ __forceinline__ void range_report(uint32_t* status, const RangeState&
   const bool bad = (f & 0xffffu) >= 0x7c00u || (f >> 16) >= 0x7c00u;
   uint32_t bits = __builtin_amdgcn_readfirstlane((int)__any(bad)) ? range_bit : 0u;
   if (__builtin_amdgcn_readfirstlane((int)r.small)) bits |= 2u;
-  if (bits && status) { if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_or(status, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  if (bits && status) { if ((FSN_TIDX & 63) == 0) __hip_atomic_fetch_or(status, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
 
 // Network description as the kernel needs it (wave-uniform).  Aux offsets follow build_geom():
@@ -573,14 +589,14 @@ __device__ __forceinline__ void unit_mfma(const char* ubase, const Frag& b, f32x
     const int dl = 0;
 #elif FSN_ABL_LDSDUMMY == 3
     typedef __attribute__((ext_vector_type(2))) int i32x2;
-    const i32x2 dh = *reinterpret_cast<const i32x2*>(ubase - (threadIdx.x & 63) * 8);
-    const i32x2 dl = *reinterpret_cast<const i32x2*>(ubase - (threadIdx.x & 63) * 8 + 1024);
+    const i32x2 dh = *reinterpret_cast<const i32x2*>(ubase - (FSN_TIDX & 63) * 8);
+    const i32x2 dl = *reinterpret_cast<const i32x2*>(ubase - (FSN_TIDX & 63) * 8 + 1024);
 #else
     typedef __attribute__((ext_vector_type(2))) int i32x2;
-    const i32x2 dh = *reinterpret_cast<const i32x2*>(ubase - (threadIdx.x & 63) * 8);
-    const i32x2 dl = *reinterpret_cast<const i32x2*>(ubase - (threadIdx.x & 63) * 8 + 512);
-    const i32x2 d2 = *reinterpret_cast<const i32x2*>(ubase - (threadIdx.x & 63) * 8 + 1024);
-    const i32x2 d3 = *reinterpret_cast<const i32x2*>(ubase - (threadIdx.x & 63) * 8 + 1536);
+    const i32x2 dh = *reinterpret_cast<const i32x2*>(ubase - (FSN_TIDX & 63) * 8);
+    const i32x2 dl = *reinterpret_cast<const i32x2*>(ubase - (FSN_TIDX & 63) * 8 + 512);
+    const i32x2 d2 = *reinterpret_cast<const i32x2*>(ubase - (FSN_TIDX & 63) * 8 + 1024);
+    const i32x2 d3 = *reinterpret_cast<const i32x2*>(ubase - (FSN_TIDX & 63) * 8 + 1536);
     asm volatile("" ::"v"(d2), "v"(d3));
 #endif
     acc = mfma16<F16>(b.lo, b.hi, acc);
@@ -833,7 +849,7 @@ __device__ __forceinline__ void kloop_block(WStream& st, const Frag (&act)[NACT]
   constexpr int NU = 2 * (KS_ACT + KS_ENC);
   uint32_t a[4], mv[3], keep;
   uint64_t gb[3];
-  const uint32_t voff = ((threadIdx.x >> 6) ^ FSN_LOADER_XOR) * (kGldsPerWave * 1024) + (threadIdx.x & 63) * 16;
+  const uint32_t voff = ((FSN_TIDX >> 6) ^ FSN_LOADER_XOR) * (kGldsPerWave * 1024) + (FSN_TIDX & 63) * 16;
   if constexpr (!TWO) {
     FSN_KLOOP_CASE(X3, 16, 0)
     FSN_KLOOP_CASE(X3, 20, 0)
@@ -910,7 +926,7 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
       constexpr int R0 = (tp * NU) % NS, OFF = (tp * NU) % UPP, PAR = tp & 1;
       hk.pre(tp);
 #if defined(FSN_PRIO) && FSN_PRIO == 4
-      if (__builtin_amdgcn_readfirstlane(threadIdx.x) & 256) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+      if (__builtin_amdgcn_readfirstlane(FSN_TIDX) & 256) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
 #endif
 #ifdef FSN_STAMP
       const uint64_t ts0 = __builtin_amdgcn_s_memtime();
@@ -966,7 +982,7 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
 #elif defined(FSN_PRIO) && FSN_PRIO == 2
     __builtin_amdgcn_s_setprio(0);
 #elif defined(FSN_PRIO) && FSN_PRIO == 4
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x) & 256) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    if (__builtin_amdgcn_readfirstlane(FSN_TIDX) & 256) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
 #endif
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -1104,7 +1120,7 @@ __device__ __forceinline__ void mlp_tile2(WStream& st, const NetDev& net, const 
                                           float (&sigma)[2], float (&rgb)[2][3]) {
   constexpr int NA = NT;
   constexpr bool F16 = PREC >= 2;
-  const int g = (threadIdx.x >> 4) & 3;
+  const int g = (FSN_TIDX >> 4) & 3;
   constexpr int D = 32 * NT;
   const int L = net.n_layers;
   const float* misc = net.aux + (L + 5) * D;
@@ -1219,7 +1235,7 @@ __device__ __forceinline__ void mlp_tile(WStream& st, const NetDev& net, const S
                                          float (&rgb)[3], const SV& sv) {
   constexpr int NA = NT;  // k-steps of 32 across the hidden width
   constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
-  const int g = (threadIdx.x >> 4) & 3;
+  const int g = (FSN_TIDX >> 4) & 3;
   constexpr int D = 32 * NT;
   const int L = net.n_layers;
   const float* misc = net.aux + (L + 5) * D;
@@ -1307,12 +1323,12 @@ __device__ __forceinline__ void load_net(const NetParams& p, const float* __rest
                                          const float* __restrict__ dir_mask_g, float* lds, NetDev& net) {
   const f32x4* src = reinterpret_cast<const f32x4*>(p.blob + p.aux_off);
   f32x4* dst = reinterpret_cast<f32x4*>(lds);
-  for (int i = threadIdx.x; i < p.aux_floats / 4; i += blockDim.x) dst[i] = src[i];
+  for (int i = FSN_TIDX; i < p.aux_floats / 4; i += blockDim.x) dst[i] = src[i];
   float* pm = lds + p.aux_floats;
   float* dm = pm + 64;
   const int npe = 3 * (1 + 2 * p.n_freqs_pos), nde = 3 * (1 + 2 * p.n_freqs_dir);
-  for (int i = threadIdx.x; i < 64; i += blockDim.x) pm[i] = (pos_mask_g && i < npe) ? pos_mask_g[i] : 1.0f;
-  for (int i = threadIdx.x; i < 32; i += blockDim.x) dm[i] = (dir_mask_g && i < nde) ? dir_mask_g[i] : 1.0f;
+  for (int i = FSN_TIDX; i < 64; i += blockDim.x) pm[i] = (pos_mask_g && i < npe) ? pos_mask_g[i] : 1.0f;
+  for (int i = FSN_TIDX; i < 32; i += blockDim.x) dm[i] = (dir_mask_g && i < nde) ? dir_mask_g[i] : 1.0f;
   net.aux = lds;
   net.pos_mask = pm;
   net.dir_mask = dm;
