@@ -155,6 +155,16 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
   prime_ring<PREC, NT>(st, ring);
   // ---- the steps of one ray group (G rays), as the kernel strings them together below
   // rays of the group into LDS: from the caller's tensors, or generated from the camera (pose + pixel index)
+  // q = n / d for the small non-negative integers of the group bookkeeping (n < 8192, 0 < d <= 512): one float
+  // multiply and a fix-up instead of hipcc's ~30-instruction integer division by a run-time divisor ((n + 0.5) / d is at
+  // least 1 / (2 d) >= 2^-10 away from every integer, the float product's error is below 8192 * 2^-23 * 2 = 2^-9 .. so
+  // the truncation is checked and corrected by one step either way)
+  auto small_div = [](int n, int d) __attribute__((always_inline)) {
+    int q = (int)(((float)n + 0.5f) * __builtin_amdgcn_rcpf((float)d));
+    q += (q + 1) * d <= n ? 1 : 0;
+    q -= q * d > n ? 1 : 0;
+    return q;
+  };
   auto load_rays = [&](int64_t r0) __attribute__((always_inline)) {
     if (a.rays_o) {
       if (tid < GRP_G * 6) {
@@ -164,7 +174,10 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
       }
     } else if (tid < GRP_G) {
       const int64_t ray = min(r0 + tid, GRP_R - 1);
-      const int h = a.cam_row0 + (int)(ray / a.cam_W), w = (int)(ray % a.cam_W);
+      // camera mode: R <= H W < 2^31 (checked at the entry), so the pixel index divides as 32-bit unsigned by a scalar -
+      // the 64-bit division by a divisor read back from LDS was ~100 instructions and the source of in-loop spills
+      const uint32_t Wc = (uint32_t)__builtin_amdgcn_readfirstlane(a.cam_W), rr = (uint32_t)ray;
+      const int h = a.cam_row0 + (int)(rr / Wc), w = (int)(rr % Wc);
       float o[3], d[3];
       pinhole_ray(a.cam_pose, S_.cam_hw, S_.cam_hh, S_.cam_f, h, w, o, d);
 #pragma unroll
@@ -175,7 +188,7 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
   // inverse-CDF resampling, sorted union (one wave per ray) -> S_.edgesF
   auto coarse_stage = [&](int64_t r0) __attribute__((always_inline)) {
     for (int e = tid; e < GRP_G * (GRP_S + 1); e += kThreads) {
-      const int g = e / (GRP_S + 1), i = e - g * (GRP_S + 1);
+      const int g = small_div(e, GRP_S + 1), i = e - g * (GRP_S + 1);
       const int64_t ray = min(r0 + g, GRP_R - 1);
       const float* ur = a.u_mode == 1 ? a.u + ray : (a.u_mode == 2 ? a.u + ray * (GRP_S + 1) : nullptr);
       S_.edgesC[e] = stratified_edge(a.near, S_.step, GRP_S, i, a.u_mode, ur);
@@ -188,7 +201,7 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
       auto slot = [&](int q) { return sub * TILE + (wave * NG + q) * 16 + (lane & 15); };
       auto source = [&](int idx) {
         const int idc = min(idx, GRP_G * GRP_S - 1);
-        const int g = idc / GRP_S, i = idc - g * GRP_S;
+        const int g = small_div(idc, GRP_S), i = idc - g * GRP_S;
         return RaySrc{S_.rays + 6 * g, S_.edgesC + g * (GRP_S + 1) + i};
       };
       if constexpr (NG == 1) {
@@ -225,7 +238,7 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
       auto slot = [&](int q) { return sub * TILE + (wave * NG + q) * 16 + (lane & 15); };
       auto source = [&](int idx) {
         const int idc = min(idx, GRP_G * GRP_SO - 1);
-        const int g = idc / GRP_SO, i = idc - g * GRP_SO;
+        const int g = small_div(idc, GRP_SO), i = idc - g * GRP_SO;
         return RaySrc{S_.rays + 6 * g, edges + g * (GRP_SO + 1) + i};
       };
       if constexpr (NG == 1) {
@@ -292,7 +305,7 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
       load_rays(r0);
       coarse_stage(r0);
       for (int e = tid; e < GRP_G * (GRP_SO + 1); e += kThreads) {
-        const int g = e / (GRP_SO + 1), i = e - g * (GRP_SO + 1);
+        const int g = small_div(e, GRP_SO + 1), i = e - g * (GRP_SO + 1);
         // (streaming: written once here, read once below, 494 MB per 800x800 frame - kept out of the way of the
         // weight streams the XCD's L2 is there for)
 #ifdef FSN_EDGES_PLAIN  // experiment: plain (L2 write-back) hand-over stores / loads
@@ -319,7 +332,7 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
       const int64_t r0 = grp * (int64_t)__builtin_amdgcn_readfirstlane(GRP_G);  // (G comes from LDS: keep r0 scalar)
       load_rays(r0);
       for (int e = tid; e < GRP_G * (GRP_SO + 1); e += kThreads) {
-        const int g = e / (GRP_SO + 1), i = e - g * (GRP_SO + 1);
+        const int g = small_div(e, GRP_SO + 1), i = e - g * (GRP_SO + 1);
 #ifdef FSN_EDGES_PLAIN
         S_.edgesF[e] = a.edges_out[min(r0 + g, GRP_R - 1) * (GRP_SO + 1) + i];
 #else
@@ -423,7 +436,7 @@ extern "C" int fsn_render_rays_fused(const fsn_mlp_desc* desc, int prec, const v
     FSN_REQUIRE(a.rays_d, FSN_E_INVALID, "fsn_render_rays_fused: rays_o without rays_d");
   } else {
     FSN_REQUIRE(a.cam_H > 0 && a.cam_W > 0 && a.cam_focal > 0 && a.cam_row0 >= 0 &&
-                    a.R <= (int64_t)(a.cam_H - a.cam_row0) * a.cam_W,
+                    (int64_t)a.cam_H * a.cam_W < (1ll << 31) && a.R <= (int64_t)(a.cam_H - a.cam_row0) * a.cam_W,
                 FSN_E_INVALID, "fsn_render_rays_fused: no rays and no valid camera (H=%d W=%d focal=%g row0=%d R=%lld)",
                 a.cam_H, a.cam_W, a.cam_focal, a.cam_row0, (long long)a.R);
   }
