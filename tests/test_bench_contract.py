@@ -44,6 +44,22 @@ def test_train_line_contract():
     assert 0.0 < j["loss"] < 1.0 and j["value"] > 1e4
 
 
+@pytest.mark.gpu
+def test_occupancy_lines_contract():
+    """`--workload occgrid` (the reference's render path in one launch) and `--workload train-occ` (its training loop
+    body): contract keys, the sample counts the FLOP figure is built from, and the fused == unfused statement."""
+    j = _run("--workload", "occgrid", "--steps", "1", "--warmup", "1")
+    assert KEYS <= set(j) and "occupancy-grid" in j["metric"] and j["unit"] == "rays/s"
+    c = j["config"]
+    assert c["rays_per_step"] == 640000 and 0.4 < c["occupied_cells"] < 0.6 and c["fused_equals_unfused_bitwise"] is True
+    assert c["marched_samples_per_ray"] > c["kept_samples_per_ray"] > 10
+    assert 0.05 < j["roofline"]["frac"] < 0.34 and j["roofline"]["kernel"] == "k_render_occ"
+    t = _run("--workload", "train-occ", "--steps", "3", "--warmup", "1")
+    assert KEYS <= set(t) and t["steps"] == 3 and "trained rays/sec (occupancy" in t["metric"]
+    assert t["config"]["rays_per_step"] == 4096 and t["config"]["marched_samples_per_ray"] > t["config"]["kept_samples_per_ray"] > 5
+    assert 0.0 < t["loss"] < 1.0 and t["value"] > 1e4
+
+
 # ---- the N>1 launcher (CPU: `--dry-run` children join a gloo group instead of touching the GPU)
 def _launch(*args, env=None):
     e = dict(os.environ)
