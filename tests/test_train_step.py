@@ -803,3 +803,49 @@ def test_nerf_gradients_over_the_activation_envelope(s):
     for name, p in m.named_parameters():
         err = _rel(p.grad, sdr[name].grad)
         assert err < 2e-4, (s, name, err)
+
+
+@pytest.mark.gpu
+def test_c_abi_backward_with_and_without_stage_arrays():
+    """fsn_nerf_train_bwd called as a C-ABI user would: without the stage arrays (factors all 1: rounds 1-2's behaviour),
+    with fresh ones (first call = calibration) and with calibrated ones, into fresh buffers and accumulating - the same
+    gradients within the 2e-4 bar, `accumulate` adds exactly, the arrays are moved by every call."""
+    from fs_nerf_amd import ops, _lib as Lb
+    from fs_nerf_amd.core.models import NeRF
+    dev = torch.device("cuda:0")
+    L, D, N = 8, 256, 1000
+    sd = O.init_nerf_state_dict(L, D, [4], 10, 4, seed=8)
+    sd["sigma.weight"] *= 16.0
+    m = NeRF(3, 3, L, D, (4,), pos_fn={"n_freqs": 10, "log_space": True}, dir_fn={"n_freqs": 4, "log_space": True})
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    ws, bs = m._tensors()
+    desc = ops.make_desc(L, D, (4,), m.pos_encoder.freqs, m.dir_encoder.freqs)
+    gen = torch.Generator().manual_seed(3)
+    x = (torch.rand(N, 3, generator=gen) * 2 - 1).to(dev)
+    d = torch.nn.functional.normalize(torch.randn(N, 3, generator=gen), dim=-1).to(dev)
+    c = torch.randn(N, 4, generator=gen).to(dev)
+    prec = Lb.FSN_PREC_FP16X3
+
+    def bwd(stage, into=None):
+        word = torch.zeros(1, dtype=torch.int32, device=dev)
+        out, work = ops.nerf_train_fwd(desc, prec, ws, bs, x, d, None, None, status=word)
+        dW, db = ops.nerf_train_bwd(desc, prec, ws, work, out, c, status=word, into=into, stage_state=stage)
+        assert int(word.item()) == 0
+        return [g.clone() for g in dW] + [g.clone().reshape(-1) for g in db]
+
+    plain = bwd(None)
+    stage = (torch.ones(L + 2, device=dev), torch.zeros(L + 2, dtype=torch.int32, device=dev))
+    first = bwd(stage)  # factors 1 during the call, measured maxima applied afterwards
+    assert all(torch.equal(a, b) for a, b in zip(plain, first)), "fresh arrays = factors of 1 = the plain call"
+    assert not bool((stage[0] == 1.0).all()) and int(stage[1].abs().max()) == 0, "the call left the next call's factors"
+    second = bwd(stage)
+    for a, b in zip(plain, second):
+        assert float((a - b).abs().max()) <= 2e-4 * float(a.abs().max())
+    # accumulate: buffers holding `second` receive the same gradients once more
+    bufW = [g.clone() for g in second[:len(ws)]]
+    bufb = [g.clone() for g in second[len(ws):]]
+    third = bwd(stage, into=(bufW, bufb))
+    fresh = bwd(stage)
+    for acc, s2, f in zip(third, second, fresh):
+        assert float((acc - (s2 + f)).abs().max()) <= 1e-6 * float((s2 + f).abs().max()) + 1e-30
