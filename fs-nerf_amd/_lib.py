@@ -14,6 +14,7 @@ FSN_PREC_BF16X3 = 0
 FSN_PREC_BF16 = 1
 FSN_PREC_FP16X3 = 2
 FSN_PREC_FP16 = 3
+FSN_PREC_FP16X3U = 4  # inference: fp16 x 3 passes, unscaled low parts, per-layer activation scales folded into the blob
 FSN_PREC_FP16X2 = 6  # two passes (weights high part only), inference only
 FSN_STATUS_FP16_RANGE = 1  # a value reached fp16 infinity
 FSN_STATUS_FP16_SMALL = 2  # a layer's activations were all below 2^-14: outside the split's float32-grade envelope
@@ -70,6 +71,9 @@ SIGNATURES = {
     "fsn_mlp_blob_bytes": (_i64, [_PD, _i]),
     "fsn_mlp_pack": (_i, [_PD, _i, _vp, _vp, _vp, _vp]),
     "fsn_mlp_pack_host": (_i, [_PD, _i, _vp, _vp, _vp]),
+    "fsn_mlp_pack_scaled": (_i, [_PD, _i, _vp, _vp, _vp, _vp, _vp]),
+    "fsn_mlp_pack_scaled_host": (_i, [_PD, _i, _vp, _vp, _vp, _vp]),
+    "fsn_mlp_layer_maxima": (_i, [_PD, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "fsn_mlp_fwd": (_i, [_PD, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "fsn_mlp_fwd_rays": (_i, [_PD, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i64, _vp, _vp, _vp]),
     "fsn_render_rays_fused": (_i, [_PD, _i, _vp, _vp, C.POINTER(RenderArgs), _vp]),

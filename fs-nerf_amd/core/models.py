@@ -11,11 +11,17 @@ fused kernel `fsn_mlp_fwd`.  In training mode with autograd enabled, `forward(x,
 instead (`_NerfTrainFn`: `fsn_nerf_train_fwd` / `_bwd`, hand-written MFMA forward-with-savers, dgrad chain and
 split-K wgrad kernels in the same precision mode).  Additions over the reference: an optional frequency mask
 (`set_freq_mask`) and the arithmetic mode `precision`:
-  "fp16x3" (default) three fp16 MFMA passes on high / scaled-low parts with a separate correction accumulator, fp32
-            accumulate: fp32-class accuracy (the 1e-4 parity mode) for hidden-layer scales from 2^-14 to 65504.  The
-            kernels raise a device flag at either end (a value reached fp16 infinity; a layer whose largest activation
-            over a wavefront is an fp16 subnormal); `forward` / `render_rays` then re-run the call in "bf16x3" and
-            keep that mode (a RuntimeWarning is issued) - never silent, inf/NaN are never returned;
+  "fp16x3" (default) three fp16 MFMA passes on high / low parts, fp32 accumulate: fp32-class accuracy (the 1e-4 parity
+            mode).  INFERENCE (round 4, `act_scaling = True`) runs the SCALED network in FSN_PREC_FP16X3U: a power of two
+            per layer, calibrated from the layers' measured activation maxima on a probe batch (`calibrate`) and folded
+            into the packed weights / biases / heads - an exact transformation - keeps every layer's activations at
+            2^4 .. 2^10 whatever the network's own scale, so the plain split (unscaled low parts, one accumulator, no
+            merge) is float32-grade and 6 % faster.  The kernels raise a device flag when the calibration no longer fits
+            the data at either end (a value reached fp16 infinity; a wavefront's layer maximum below 2^-4): the host
+            re-calibrates and re-runs the call (never silent, inf/NaN are never returned); only when that does not help
+            it continues in "bf16x3" with a RuntimeWarning.  TRAINING (forward-with-savers / backward / weight
+            gradients) keeps round 3's arithmetic (FSN_PREC_FP16X3: low parts scaled by 2^11, own correction accumulator:
+            float32-grade from 2^-14 to 65504 with no calibration), as does inference with `act_scaling = False`;
   "bf16x3"  the same split on bf16 parts: no range limit, ~1e-5 per product;
   "fp16x2"  two passes (weights high part only): measured accuracy in DESIGN.md, not a parity mode;
   "bf16" / "fp16"  one pass (BASELINE config 5), tolerance stated in the tests.
@@ -96,9 +102,11 @@ class _NerfTrainFn(torch.autograd.Function):
         model = ctx.model
         d_out = d_out.contiguous()
         stage = model._bwd_stage_state(d_out.device) if model.fp16_family(ctx.prec) else None
-        if stage is not None and not model._bwd_calibrated:
+        if stage is not None and not model._bwd_calibrated and d_out.shape[0] > 0:
             # first backward of this model in an fp16 mode: one throw-away pass to measure the per-stage gradient
-            # magnitudes (delayed scaling needs a previous call; its own status word, scratch outputs)
+            # magnitudes (delayed scaling needs a previous call; its own status word, scratch outputs).  A call without
+            # samples - the all-background first batch of an empty occupancy grid - launches nothing and calibrates
+            # nothing: the next one with samples does.
             ops.nerf_train_bwd(ctx.desc, ctx.prec, ctx.weights, ctx.work, ctx.out, d_out,
                                status=torch.zeros_like(ctx.word) if ctx.word is not None else None, stage_state=stage)
             model._bwd_calibrated = True
@@ -113,14 +121,20 @@ class _NerfTrainFn(torch.autograd.Function):
         # training calls; it then warns and continues in bf16x3.
         if ctx.word is not None:
             ops.step_flag(d_out.device).bitwise_or_(ctx.word)
-            model._train_status(d_out.device).bitwise_or_(ctx.word)
+            model._train_status(d_out.device)[0:1].bitwise_or_(ctx.word)
             model._train_calls += 1
             if model.range_check and model._train_calls % model.range_check_every == 0:
-                model._guard_weights("training steps")
-                bits = model._read_train_status(d_out.device)
+                model._guard_weights("training steps", training=True)
+                bits, sampler_bits = model._read_train_status(d_out.device)
                 if bits:
                     model.fall_back("training steps (an overflowing step's gradients were zeroed on the device and its "
-                                    "optimizer update skipped)", bits)
+                                    "optimizer update skipped)", bits, scaled=False)
+                # The sampler's density pass in front of the training forward is an INFERENCE launch (scaled fp16x3):
+                # a flag there says its per-layer scales no longer fit the weights being trained (the step was skipped
+                # on the device); the next sampler call re-calibrates on its own rays.  Also every 4th look, flag or
+                # not, so that the scales follow the network long before a guard trips.
+                if sampler_bits or (model._train_calls // model.range_check_every) % 4 == 0:
+                    model._needs_calibration = True
         if sink:
             return (None, None, None) + (None,) * (2 * n)
         db = [g.reshape(-1) for g in db]
@@ -169,6 +183,16 @@ class NeRF(nn.Module):
         self.dir_mask: Optional[Tensor] = None
         self._packed = None
         self._packed_key = None
+        # per-layer activation scaling of the fp16x3 inference path (module docstring)
+        self.act_scaling = True
+        self.act_target_exp = self.ACT_TARGET_EXP
+        self._act_exps: Optional[list] = None   # n_layers + 2 exponents (kernel GEMM order), None = not calibrated
+        self._calib_key = None                  # parameter versions the calibration was made with
+        self._calib_moves = 0                   # target moves since then (same weights, data did not fit)
+        self._needs_calibration = False
+        self._calib_blob = None
+        self.calibrations = 0                   # statistics: calibration launches / range events (fall-backs and
+        self.range_events = 0                   # re-calibrations) of this model
 
     # -- additions -----------------------------------------------------------------
     def set_freq_mask(self, pos_mask: Optional[Tensor], dir_mask: Optional[Tensor] = None) -> None:
@@ -195,31 +219,47 @@ class NeRF(nn.Module):
         return st
 
     def _train_status(self, dev) -> Tensor:
-        """This model's accumulated training range word (device; OR of its calls' words since the last host look)."""
+        """This model's accumulated training range words (device int32 [2]; OR of its calls' words since the last host
+        look): [0] the training kernels' (forward-with-savers / backward), [1] the sampler's density pass (an inference
+        launch in front of the training forward, rendering.py)."""
         w = self._train_word
         if w is None or w.device != dev:
-            w = self._train_word = torch.zeros(1, dtype=torch.int32, device=dev)
+            w = self._train_word = torch.zeros(2, dtype=torch.int32, device=dev)
         return w
 
-    def _read_train_status(self, dev) -> int:
-        """Host look at the accumulated word (one 4-byte read-back) and clear.  Data-parallel runs take the MAX over
-        the ranks first (every rank makes the same number of training calls, so all of them are here together): a
-        rank that overflowed and one that did not must not continue in different arithmetic."""
+    def _read_train_status(self, dev) -> Tuple[int, int]:
+        """Host look at the accumulated words (one 8-byte read-back) and clear -> (training kernels' bits, sampler's
+        bits).  Data-parallel runs take the MAX over the ranks first (every rank makes the same number of training
+        calls, so all of them are here together): a rank that overflowed and one that did not must not continue in
+        different arithmetic."""
         w = self._train_status(dev)
         from ..shard import max_bits_over_ranks
-        local = int(w.item())
+        local, samp = (int(v) for v in w.tolist())
         if local & L.FSN_STATUS_GRAD_RANGE:  # delayed gradient scaling skipped a step (and lowered a stage): no fall-back
             self.grad_overflow_looks += 1
-        # (MAX of bit masks 0..3: both bits lead to the same fall-back, so the largest mask is enough)
-        bits = max_bits_over_ranks(local & (L.FSN_STATUS_FP16_RANGE | L.FSN_STATUS_FP16_SMALL), dev)
-        if local or bits:
+        env = L.FSN_STATUS_FP16_RANGE | L.FSN_STATUS_FP16_SMALL
+        # (MAX of bit masks 0..3: both bits lead to the same action, so the largest mask is enough; the two words are
+        # reduced separately - a MAX over a combined mask would lose the smaller word's bits)
+        bits = max_bits_over_ranks(local & env, dev)
+        sbits = max_bits_over_ranks(samp & env, dev)
+        if local or samp or bits or sbits:
             w.zero_()
-        return bits & (L.FSN_STATUS_FP16_RANGE | L.FSN_STATUS_FP16_SMALL)
+        return bits & env, sbits & env
 
-    def fall_back(self, what: str, bits: int = L.FSN_STATUS_FP16_RANGE) -> None:
-        """An fp16-mode launch reported values outside the mode's envelope (|v| >= 65504, or a layer whose activations
-        all sat below 2^-14): continue in the bf16 mode of the same pass structure, which has float32's range.  Never
-        silent."""
+    def fall_back(self, what: str, bits: int = L.FSN_STATUS_FP16_RANGE, probe=None, earlier_invalid: bool = False,
+                  scaled: bool = True) -> None:
+        """An fp16-mode launch reported values outside the mode's envelope; the caller re-runs the call afterwards.
+        Scaled inference (`infer_prec() == FSN_PREC_FP16X3U`, and `scaled`: the report came from an inference launch):
+        the calibration did not fit the data - re-calibrate on `probe` (`_recalibrate`) and stay in fp16x3.  Otherwise,
+        or when that does not help: continue in the bf16 mode of the same pass structure, which has float32's range,
+        with a RuntimeWarning.  Never silent: `earlier_invalid` (deferred range checks) warns in the re-calibrated case
+        too, because results already handed out were invalid."""
+        self.range_events += 1
+        if scaled and self.infer_prec() == L.FSN_PREC_FP16X3U and self._recalibrate(bits, probe):
+            if earlier_invalid:
+                warnings.warn(f"fs-nerf HIP path: {what}: the per-layer activation scales did not fit the data "
+                              f"({ops.describe_flags(bits)}); re-calibrated", RuntimeWarning, stacklevel=3)
+            return
         new = self.FALLBACK.get(self.precision, "bf16x3")
         warnings.warn(f"fs-nerf HIP path: {what}: hidden activations left the fp16 range envelope of precision "
                       f"'{self.precision}' ({ops.describe_flags(bits)}); re-running / continuing in '{new}'",
@@ -231,6 +271,116 @@ class NeRF(nn.Module):
     def _tensors(self):
         mods = list(self.layers) + [self.sigma, self.connection, self.branch, self.rgb]
         return [m.weight for m in mods], [m.bias for m in mods]
+
+    # -- per-layer activation scaling (fp16x3 inference) ---------------------------------
+    ACT_TARGET_EXP = 10  # a layer's largest probe activation is scaled into (2^9, 2^10]: 2^6 of headroom to 65504
+    PROBE_MAX = 16384    # probe samples per calibration launch
+
+    def infer_prec(self) -> int:
+        """Arithmetic mode of the INFERENCE kernels (fsn_mlp_fwd, fsn_render_rays_fused, fsn_render_rays_occgrid)."""
+        if self.precision == "fp16x3" and self.act_scaling:
+            return L.FSN_PREC_FP16X3U
+        return self.PRECISIONS[self.precision]
+
+    def _param_key(self):
+        ws, bs = self._tensors()
+        return tuple((t.data_ptr(), t._version) for t in ws + bs)
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._act_exps = None  # other weights: calibrate again on the next inference call
+        return out
+
+    def _default_probe(self, dev):
+        g = torch.Generator(device="cpu").manual_seed(0)
+        x = (torch.rand(4096, 3, generator=g) * 4.0 - 2.0).to(dev)
+        d = torch.nn.functional.normalize(torch.randn(4096, 3, generator=g), dim=-1).to(dev)
+        return x, d
+
+    @torch.no_grad()
+    def calibrate(self, probe=None, keep_if_close: bool = False) -> list:
+        """Measure every layer's largest |activation| on a probe batch and choose the power-of-two scales of the
+        fp16x3 inference path.  `probe`: (x [n,3], dirs [n,3]) tensors or a callable returning them - sample positions
+        and directions like those the network is evaluated on (the call sites build them from their rays); None = a
+        fixed default (uniform in [-2,2]^3, random unit directions).  One bf16x3 launch of the UNSCALED network on at
+        most PROBE_MAX samples (`fsn_mlp_layer_maxima`) and one small read-back.  `keep_if_close`: an existing exponent
+        is kept while it still puts the layer's maximum within [2^-3, 2^1] of the target (periodic re-calibration
+        during training: no flapping between neighbouring powers of two).  -> the exponents."""
+        import math
+        ws, bs = self._tensors()
+        dev = ws[0].device
+        if callable(probe):
+            probe = probe()
+        x, d = probe if probe is not None else self._default_probe(dev)
+        x, d = x.reshape(-1, 3).to(dev, torch.float32), d.reshape(-1, 3).to(dev, torch.float32)
+        if x.shape[0] == 0:
+            x, d = self._default_probe(dev)
+        if x.shape[0] > self.PROBE_MAX:
+            idx = torch.linspace(0, x.shape[0] - 1, self.PROBE_MAX, device=dev).long()
+            x, d = x[idx], d[idx]
+        desc = ops.make_desc(self.n_layers, self.d_hidden, self.skip, self.pos_encoder.freqs, self.dir_encoder.freqs)
+        if self._calib_blob is None or self._calib_blob.blob.device != dev:
+            self._calib_blob = ops.PackedMLP(desc, L.FSN_PREC_BF16X3, dev)
+        self._calib_blob.pack(ws, bs)
+        maxima = ops.mlp_layer_maxima(self._calib_blob, x.contiguous(), d.contiguous(), self._mask(self.pos_mask, dev),
+                                      self._mask(self.dir_mask, dev))
+        # largest |weight| per GEMM, activation columns and encoding columns separately (the scaled weights must stay
+        # inside fp16 too): one stacked reduction, read back together with the maxima
+        D, n = self.d_hidden, self.n_layers
+        mods = list(self.layers) + [self.connection, self.branch]
+        wmax = []
+        for g, m in enumerate(mods):
+            w = m.weight.detach().abs()
+            na = 0 if g == 0 else D
+            wmax.append(w[:, :na].amax() if na else w.new_zeros(()))
+            wmax.append(w[:, na:].amax() if w.shape[1] > na else w.new_zeros(()))
+        host = torch.cat([maxima, torch.stack(wmax).to(torch.float32)]).cpu().tolist()  # the one host sync
+        amax, wmx = host[:n + 2], host[n + 2:]
+        T = int(self.act_target_exp)
+        old = self._act_exps
+        exps = []
+        for g, v in enumerate(amax):
+            if not math.isfinite(v):
+                raise RuntimeError(f"NeRF.calibrate: layer {g} produced non-finite activations on the probe batch")
+            if v <= 0.0:
+                e = old[g] if old is not None else 0  # dead layer on the probe: its scale does not matter
+            else:
+                e = T - math.ceil(math.log2(v))
+                if keep_if_close and old is not None and 2.0 ** (T - 3) <= v * 2.0 ** old[g] <= 2.0 ** (T + 1):
+                    e = old[g]
+            exps.append(max(-60, min(60, e)))
+        # scaled weights: W_g * 2^(e_g - e_prev) on activation columns, W_g * 2^e_g on encoding columns, below 2^15
+        for g in range(n + 2):
+            prev = 0 if g == 0 else (exps[n - 1] if g == n else (exps[n] if g == n + 1 else exps[g - 1]))
+            for wm, sh in ((wmx[2 * g], exps[g] - prev), (wmx[2 * g + 1], exps[g])):
+                if wm > 0.0 and math.isfinite(wm):
+                    over = math.ceil(math.log2(wm)) + sh - 15
+                    if over > 0:
+                        exps[g] -= over
+        self._act_exps = exps
+        self._calib_key = self._param_key()
+        self._needs_calibration = False
+        self.calibrations += 1
+        return exps
+
+    def _recalibrate(self, bits: int, probe) -> bool:
+        """A scaled-mode launch reported that its calibration does not fit the data.  Other weights than the calibration
+        saw: measure again.  Same weights: the probe was not representative - move the target (overflow: 2^4 more
+        headroom; small: 2^3 less) and measure again, at most three times.  False: give up (bf16x3)."""
+        if self._act_exps is not None and self._calib_key == self._param_key():
+            if self._calib_moves >= 3 or bits == (L.FSN_STATUS_FP16_RANGE | L.FSN_STATUS_FP16_SMALL):
+                return False
+            self._calib_moves += 1
+            self.act_target_exp += -4 if bits & L.FSN_STATUS_FP16_RANGE else 3
+            if not 2 <= self.act_target_exp <= 14:
+                return False
+        else:
+            self._calib_moves = 0
+        try:
+            self.calibrate(probe)
+        except RuntimeError:
+            return False
+        return True
 
     def _weights_below_envelope(self) -> bool:
         """fp16 modes: True when some layer's LARGEST weight is below 2^-20.  High parts under 2^-14 are fp16 subnormals
@@ -244,26 +394,38 @@ class NeRF(nn.Module):
             m = torch.stack([mod.weight.detach().abs().amax() for mod in mods])
             return bool(((m > 0) & (m < 2.0 ** -20)).any())
 
-    def _guard_weights(self, what: str) -> None:
+    def _guard_weights(self, what: str, training: bool = False) -> None:
+        # (scaled inference brings every layer's weights to the activations' scale: the check is about the unscaled
+        # arithmetic of training and of `act_scaling = False`)
+        if not training and self.infer_prec() == L.FSN_PREC_FP16X3U:
+            return
         if self.range_check and self.weight_check and self.fp16_family(self.PRECISIONS[self.precision]) and \
                 self._weights_below_envelope():
-            self.fall_back(what + " (a layer's largest weight is below 2^-20)", L.FSN_STATUS_FP16_SMALL)
+            self.fall_back(what + " (a layer's largest weight is below 2^-20)", L.FSN_STATUS_FP16_SMALL, scaled=False)
 
-    def packed(self) -> ops.PackedMLP:
-        """Weights in the MFMA streaming layout; re-packed when any parameter changed."""
+    def packed(self, probe=None) -> ops.PackedMLP:
+        """Weights in the MFMA streaming layout of the inference kernels; re-packed when any parameter changed.  Scaled
+        fp16x3 inference: the first call (and the first one after `load_state_dict` or a request of the training
+        loop's periodic look) calibrates the per-layer scales on `probe` (see `calibrate`) first."""
         ws, bs = self._tensors()
-        key = (self.precision, ws[0].device) + tuple((t.data_ptr(), t._version) for t in ws + bs)
+        scaled = self.infer_prec() == L.FSN_PREC_FP16X3U
+        if scaled and (self._act_exps is None or self._needs_calibration):
+            self.calibrate(probe, keep_if_close=self._act_exps is not None)
+        exps = tuple(self._act_exps) if scaled else None
+        key = (self.precision, ws[0].device, exps) + self._param_key()
         if self._packed is None or key != self._packed_key:
             if self._pack_calls % max(1, int(self.range_check_every)) == 0:
                 self._guard_weights("NeRF.packed")
-                key = (self.precision,) + key[1:]
+                scaled = self.infer_prec() == L.FSN_PREC_FP16X3U
+                exps = tuple(self._act_exps) if scaled else None
+                key = (self.precision, key[1], exps) + key[3:]
             self._pack_calls += 1
             desc = ops.make_desc(self.n_layers, self.d_hidden, self.skip, self.pos_encoder.freqs,
                                  self.dir_encoder.freqs)
-            if self._packed is None or self._packed.prec != self.PRECISIONS[self.precision] \
-                    or self._packed.blob.device != ws[0].device:
-                self._packed = ops.PackedMLP(desc, self.PRECISIONS[self.precision], ws[0].device)
-            self._packed.pack(ws, bs)
+            prec = self.infer_prec()
+            if self._packed is None or self._packed.prec != prec or self._packed.blob.device != ws[0].device:
+                self._packed = ops.PackedMLP(desc, prec, ws[0].device)
+            self._packed.pack(ws, bs, exps)
             self._packed_key = key
         return self._packed
 
@@ -281,11 +443,42 @@ class NeRF(nn.Module):
             return _NerfTrainFn.apply(self, (rays_o, rays_d, ray_indices, t_starts, t_ends), None, *ws, *bs)
         dev = rays_o.device
         args = (rays_o, rays_d, ray_indices, t_starts, t_ends, full, self._mask(self.pos_mask, dev), self._mask(self.dir_mask, dev))
-        out = ops.mlp_fwd_rays(self.packed(), *args)
-        bits = ops.range_flags(dev) if self.range_check is True and self.fp16_family(self.PRECISIONS[self.precision]) else 0
-        if bits:
-            self.fall_back("NeRF.forward_rays", bits)
-            out = ops.mlp_fwd_rays(self.packed(), *args)
+
+        def probe():
+            n = ray_indices.numel()
+            idx = torch.linspace(0, max(n - 1, 0), min(n, self.PROBE_MAX), device=dev).long()
+            ri = ray_indices[idx].long()
+            d = rays_d[ri]
+            return rays_o[ri] + d * (t_starts[idx] + t_ends[idx])[:, None] / 2.0, d
+
+        return self._guarded(dev, "NeRF.forward_rays", probe, lambda: ops.mlp_fwd_rays(self.packed(probe), *args))
+
+    def _guarded(self, dev, what: str, probe, launch):
+        """`launch()` under the fp16 range guard of an inference call.  range_check True: read the launch's word back
+        (one host sync); a flagged call is re-run after `fall_back` (re-calibration, or bf16x3).  "deferred": no wait -
+        the word of the PREVIOUS launch is looked at now (ops.range_poll), this launch posts its own for the next call /
+        the end of the frame (render_frame) to look at.  False: never look."""
+        f16 = lambda: self.fp16_family(self.PRECISIONS[self.precision])
+        if not self.range_check or not f16():
+            return launch()
+        if self.range_check == "deferred":
+            bits = ops.range_poll(dev)
+            if bits:
+                self.fall_back("an EARLIER call (deferred range check: its outputs are invalid)", bits, probe,
+                               earlier_invalid=True)
+            out = launch()
+            if f16():
+                ops.range_post(dev)
+            return out
+        out = launch()
+        for _ in range(5):
+            bits = ops.range_flags(dev)
+            if not bits:
+                break
+            self.fall_back(what, bits, probe)
+            out = launch()
+            if not f16():
+                break
         return out
 
     # -- reference surface ---------------------------------------------------------
@@ -298,9 +491,13 @@ class NeRF(nn.Module):
             ws, bs = self._tensors()
             return _NerfTrainFn.apply(self, x, dirs, *ws, *bs)
         dev = x.device
-        out = ops.mlp_fwd(self.packed(), x, dirs, self._mask(self.pos_mask, dev), self._mask(self.dir_mask, dev))
-        bits = ops.range_flags(dev) if self.range_check and self.fp16_family(self.PRECISIONS[self.precision]) else 0
-        if bits:
-            self.fall_back("NeRF.forward", bits)
-            out = ops.mlp_fwd(self.packed(), x, dirs, self._mask(self.pos_mask, dev), self._mask(self.dir_mask, dev))
-        return out
+
+        def probe():
+            xs = x.reshape(-1, 3)
+            if dirs is not None:
+                return xs, dirs.reshape(-1, 3)
+            return xs, torch.tensor([0.0, 0.0, 1.0], device=dev).expand_as(xs)  # (density only: any direction)
+
+        return self._guarded(dev, "NeRF.forward", probe,
+                             lambda: ops.mlp_fwd(self.packed(probe), x, dirs, self._mask(self.pos_mask, dev),
+                                                 self._mask(self.dir_mask, dev)))

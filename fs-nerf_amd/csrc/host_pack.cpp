@@ -36,3 +36,12 @@ extern "C" int fsn_mlp_pack_host(const fsn_mlp_desc* desc, int prec, const float
   if (rc != FSN_OK) set_error("fsn_mlp_pack_host: %s", why);
   return rc;
 }
+
+extern "C" int fsn_mlp_pack_scaled_host(const fsn_mlp_desc* desc, int prec, const float* const* weights,
+                                        const float* const* biases, const int32_t* layer_exps, void* blob_host) {
+  if (!blob_host) { set_error("fsn_mlp_pack_scaled_host: null blob"); return FSN_E_INVALID; }
+  const char* why;
+  const int rc = fsn::pack_blob_host(desc, prec, weights, biases, blob_host, &why, layer_exps);
+  if (rc != FSN_OK) set_error("fsn_mlp_pack_scaled_host: %s", why);
+  return rc;
+}

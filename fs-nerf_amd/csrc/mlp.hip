@@ -4,6 +4,7 @@
 // x3 modes: pinned one-unit-ahead LDS prefetch of the A operands (mlp_dev.hpp).  +6 % on these kernels; the fused
 // render kernel keeps the compiler's own read placement (with its larger live state the pinned form spills more).
 #define FSN_X3_PF1
+#define FSN_BF16X3_ONEACC 1  // inference: bf16x3 accumulates its three products in one tile (mlp_dev.hpp)
 #include "mlp_dev.hpp"
 #include "mlp_layout.hpp"
 #include "mlp_pack.hpp"
@@ -40,9 +41,9 @@ __global__ void k_pack_aux(PackArgs a, char* __restrict__ blob) {
 }
 
 static int fill_pack_args(const fsn_mlp_desc* d, int prec, const float* const* W, const float* const* b,
-                          PackArgs& a) {
+                          PackArgs& a, const int32_t* exps = nullptr) {
   const char* why;
-  const int rc = fill_pack_args_raw(d, prec, W, b, a, &why);
+  const int rc = fill_pack_args_raw(d, prec, W, b, a, &why, exps);
   FSN_REQUIRE(rc == FSN_OK, rc, "mlp_pack: %s", why);
   return FSN_OK;
 }
@@ -166,6 +167,86 @@ __global__ __launch_bounds__(kThreads) void k_mlp_fwd(MlpFwdArgs a) {
   st.drain();
 }
 
+// ------------------------------------------------------------------ per-layer activation maxima (calibration)
+// fsn_mlp_layer_maxima: the full forward of k_mlp_fwd with a hook that keeps, per GEMM, the largest |output after its
+// activation| - what the host turns into the per-layer power-of-two scales of FSN_PREC_FP16X3U (fsn_mlp_pack_scaled).
+struct MaxSave {
+  static constexpr bool kSave = false;
+  struct Hook {
+    static constexpr bool kZeroInit = false;
+    static constexpr bool kPacked = false;
+    static constexpr bool kLayerEnd = false;
+    float m;
+    __device__ __forceinline__ void pre(int) {}
+    __device__ __forceinline__ void post(int, float (&v)[8]) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));
+    }
+  };
+  float* wave_max;  // LDS: this wave's kMaxLayers + 2 running maxima
+  __device__ __forceinline__ Hook hidden(int) const { return Hook{0.f}; }
+  __device__ __forceinline__ Hook branch() const { return Hook{0.f}; }
+  __device__ __forceinline__ uint32_t* enc_pos(int) const { return nullptr; }
+  __device__ __forceinline__ uint32_t* enc_dir(int) const { return nullptr; }
+  __device__ __forceinline__ void layer_done(int l, Hook& hk) const {
+    float m = hk.m;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) wave_max[l] = fmaxf(wave_max[l], m);
+  }
+};
+
+template <int NT, int PREC>
+__global__ __launch_bounds__(kThreads) void k_mlp_maxima(MlpFwdArgs a, float* __restrict__ maxima) {
+  constexpr int TILE = 128, NSLOT = kMaxLayers + 2;
+  __shared__ __attribute__((aligned(1024))) char smem[kRingBytes + (kAuxCapFloats + 96) * 4 + TILE * 6 * 4 + kWaves * NSLOT * 4];
+  float* aux_lds = reinterpret_cast<float*>(smem + kRingBytes);
+  float* in_lds = aux_lds + kAuxCapFloats + 96;
+  float* max_lds = in_lds + TILE * 6;
+  NetDev net;
+  load_net(a.net, a.pos_mask, a.dir_mask, aux_lds, net);
+  net.status = nullptr;  // (a calibration pass reports maxima, not range bits: inf shows as inf)
+  for (int i = threadIdx.x; i < kWaves * NSLOT; i += blockDim.x) max_lds[i] = 0.f;
+  __syncthreads();
+  const int64_t ntiles = (a.n + TILE - 1) / TILE;
+  WStream st;
+  st.init(smem, nullptr, 0, 0, a.net.blob + a.net.stream_off, (uint32_t)a.net.nph_full, 1);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  ARing ring;
+  prime_ring<PREC, NT>(st, ring);
+  const MaxSave sv{max_lds + wave * NSLOT};
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if (lane < 16) {
+      const int64_t s = tile * TILE + wave * 16 + lane;
+      const int64_t sc = s < a.n ? s : a.n - 1;  // (tail slots repeat the last sample: maxima unchanged)
+      float* q = in_lds + (wave * 16 + lane) * 6;
+      q[0] = a.x[3 * sc]; q[1] = a.x[3 * sc + 1]; q[2] = a.x[3 * sc + 2];
+      q[3] = a.dirs[3 * sc]; q[4] = a.dirs[3 * sc + 1]; q[5] = a.dirs[3 * sc + 2];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const TileSrc src{in_lds + (wave * 16 + (lane & 15)) * 6};
+    float sigma, rgb[3] = {0.f, 0.f, 0.f};
+    mlp_tile<NT, PREC, true>(st, net, src, ring, sigma, rgb, sv);
+  }
+  st.drain();
+  __syncthreads();
+  if ((int)threadIdx.x < a.net.n_layers + 2) {
+    float m = 0.f;
+    for (int w = 0; w < kWaves; ++w) m = fmaxf(m, max_lds[w * NSLOT + threadIdx.x]);
+    // non-negative floats (and +inf) order like their bit patterns
+    atomicMax(reinterpret_cast<unsigned int*>(maxima) + threadIdx.x, __float_as_uint(m));
+  }
+}
+
+template <int NT, int PREC>
+static int launch_mlp_maxima(const MlpFwdArgs& a, float* maxima, int cus, hipStream_t s) {
+  const int64_t ntiles = (a.n + 127) / 128;
+  const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
+  k_mlp_maxima<NT, PREC><<<grid, kThreads, 0, s>>>(a, maxima);
+  FSN_LAUNCH_CHECK("k_mlp_maxima");
+  return FSN_OK;
+}
+
 template <int NT, int PREC>
 static int launch_mlp_fwd(const MlpFwdArgs& a, int cus, hipStream_t s) {
   constexpr int TILE = 128 * groups_per_wave<NT, PREC>();
@@ -192,9 +273,14 @@ extern "C" int64_t fsn_mlp_blob_bytes(const fsn_mlp_desc* desc, int prec) {
 
 extern "C" int fsn_mlp_pack(const fsn_mlp_desc* desc, int prec, const float* const* weights, const float* const* biases,
                             void* blob, fsn_stream_t stream) {
+  return fsn_mlp_pack_scaled(desc, prec, weights, biases, nullptr, blob, stream);
+}
+
+extern "C" int fsn_mlp_pack_scaled(const fsn_mlp_desc* desc, int prec, const float* const* weights,
+                                   const float* const* biases, const int32_t* layer_exps, void* blob, fsn_stream_t stream) {
   FSN_REQUIRE(blob, FSN_E_INVALID, "fsn_mlp_pack: null blob");
   PackArgs a;
-  const int rc = fill_pack_args(desc, prec, weights, biases, a);
+  const int rc = fill_pack_args(desc, prec, weights, biases, a, layer_exps);
   if (rc != FSN_OK) return rc;
   const int64_t n_pieces = (int64_t)a.G.nph_full * kPhaseBytes / 16;
   k_pack_stream<<<(unsigned)((n_pieces + 255) / 256), 256, 0, as_stream(stream)>>>(a, static_cast<char*>(blob), n_pieces);
@@ -214,6 +300,15 @@ extern "C" int fsn_mlp_pack_host(const fsn_mlp_desc* desc, int prec, const float
   return FSN_OK;
 }
 
+extern "C" int fsn_mlp_pack_scaled_host(const fsn_mlp_desc* desc, int prec, const float* const* weights,
+                                        const float* const* biases, const int32_t* layer_exps, void* blob_host) {
+  FSN_REQUIRE(blob_host, FSN_E_INVALID, "fsn_mlp_pack_scaled_host: null blob");
+  const char* why;
+  const int rc = pack_blob_host(desc, prec, weights, biases, blob_host, &why, layer_exps);
+  FSN_REQUIRE(rc == FSN_OK, rc, "fsn_mlp_pack_scaled_host: %s", why);
+  return FSN_OK;
+}
+
 static int mlp_fwd_any(const char* who, const fsn_mlp_desc* desc, int prec, const void* blob, MlpFwdArgs a, uint32_t* status,
                        fsn_stream_t stream) {
   FSN_REQUIRE(desc && a.n >= 0, FSN_E_INVALID, "%s: bad arguments", who);
@@ -229,6 +324,7 @@ static int mlp_fwd_any(const char* who, const fsn_mlp_desc* desc, int prec, cons
   a.net = make_net_params(*desc, G, blob, status);
   hipStream_t s = as_stream(stream);
   if (prec == FSN_PREC_FP16X2) return desc->d_hidden == 256 ? launch_mlp_fwd<8, 6>(a, cus, s) : launch_mlp_fwd<4, 6>(a, cus, s);
+  if (prec == FSN_PREC_FP16X3U) return desc->d_hidden == 256 ? launch_mlp_fwd<8, 4>(a, cus, s) : launch_mlp_fwd<4, 4>(a, cus, s);
   const int key = (desc->d_hidden == 256 ? 4 : 0) + prec;
   switch (key) {
     case 0: return launch_mlp_fwd<4, 0>(a, cus, s);
@@ -258,4 +354,27 @@ extern "C" int fsn_mlp_fwd_rays(const fsn_mlp_desc* desc, int prec, const void* 
   a.rays_o = rays_o; a.rays_d = rays_d; a.ri = ray_indices; a.t0 = t_starts; a.t1 = t_ends; a.full = full ? 1 : 0;
   a.pos_mask = pos_mask; a.dir_mask = dir_mask; a.n = n; a.out = out;
   return mlp_fwd_any("fsn_mlp_fwd_rays", desc, prec, blob, a, status, stream);
+}
+
+extern "C" int fsn_mlp_layer_maxima(const fsn_mlp_desc* desc, int prec, const void* blob, const float* x, const float* dirs,
+                                    const float* pos_mask, const float* dir_mask, int64_t n, float* maxima,
+                                    fsn_stream_t stream) {
+  FSN_REQUIRE(desc && n >= 0, FSN_E_INVALID, "fsn_mlp_layer_maxima: bad arguments");
+  FSN_REQUIRE(prec == FSN_PREC_BF16X3 || prec == FSN_PREC_FP16X3U, FSN_E_UNSUPPORTED,
+              "fsn_mlp_layer_maxima: precision mode %d (FSN_PREC_BF16X3 or FSN_PREC_FP16X3U)", prec);
+  NetGeom G;
+  const char* why;
+  const int rc = build_geom(*desc, prec, G, &why);
+  FSN_REQUIRE(rc == FSN_OK, rc, "fsn_mlp_layer_maxima: %s", why);
+  if (n == 0) return FSN_OK;
+  FSN_REQUIRE(blob && x && dirs && maxima, FSN_E_INVALID, "fsn_mlp_layer_maxima: null pointer");
+  FSN_REQUIRE(G.aux_floats <= kAuxCapFloats, FSN_E_UNSUPPORTED, "fsn_mlp_layer_maxima: network too deep for the LDS aux area");
+  const int cus = fsn_device_cus();
+  if (cus <= 0) return FSN_E_HIP;
+  MlpFwdArgs a{};
+  a.x = x; a.dirs = dirs; a.pos_mask = pos_mask; a.dir_mask = dir_mask; a.n = n;
+  a.net = make_net_params(*desc, G, blob, nullptr);
+  hipStream_t s = as_stream(stream);
+  if (prec == FSN_PREC_BF16X3) return desc->d_hidden == 256 ? launch_mlp_maxima<8, 0>(a, maxima, cus, s) : launch_mlp_maxima<4, 0>(a, maxima, cus, s);
+  return desc->d_hidden == 256 ? launch_mlp_maxima<8, 4>(a, maxima, cus, s) : launch_mlp_maxima<4, 4>(a, maxima, cus, s);
 }

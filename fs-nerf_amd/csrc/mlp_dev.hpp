@@ -16,6 +16,11 @@
 //    kLoScaleF16) so that they are normal fp16 numbers for |v| down to ~6e-5: fp16x3 ~ fp32 accuracy
 //    for layer scales from 2^-14 to 65504 (both ends are detected, never silent); bf16x3
 //    ~1e-5 per product, float32's range; FSN_PREC_BF16 / FSN_PREC_FP16: one pass.
+//  * FSN_PREC_FP16X3U (PREC 4, round 4; inference kernels): the same three products with UNSCALED low parts, all into one
+//    accumulator tile, no merge and a three-instruction split in the epilogue (rounds 1-2's arithmetic, 6 % faster).  It
+//    is float32-grade because the packed network is SCALED: a power of two per layer, folded into weights / biases /
+//    heads by the packer (mlp_pack.hpp) and calibrated from the layers' measured maxima, keeps every layer's activations
+//    at 2^4 .. 2^10 whatever the network's own scale.  Both ends of the calibration are detected (range_layer_end).
 //  * sigma (256 -> 1) and rgb (128 -> 3) heads are fp32 VALU dot products on the accumulators.
 #pragma once
 #include "common.hpp"
@@ -111,6 +116,15 @@ constexpr int kTRow = 16;            // T-layout: samples of a chunk (consecutiv
 __host__ __device__ constexpr int64_t t_layout_off(int NPL, int P, int pr, int s) {
   return (((int64_t)(s >> 4) * P + pr) * kTRow + (s & 15)) * NPL;
 }
+
+// properties of the arithmetic mode PREC (FSN_PREC_*)
+constexpr bool prec_f16(int P) { return P >= 2; }
+constexpr bool prec_x3(int P) { return (P & 1) == 0; }
+constexpr bool prec_lo_scaled_k(int P) { return P == 2 || P == 6; }  // fp16 low parts stored as fp16((v - high) * 2^11)
+#ifndef FSN_BF16X3_ONEACC  // bf16x3 (low parts unscaled anyway) on the one-accumulator form too in the INFERENCE kernels:
+#define FSN_BF16X3_ONEACC 0  // 383.3 against 399.3 ms per headline frame (render.hip / render_occ.hip / mlp.hip set it)
+#endif
+constexpr bool prec_one_acc(int P) { return P == 4 || (FSN_BF16X3_ONEACC && P == 0); }  // one accumulator per tile, no merge
 
 struct Frag {  // one k-step (32 features x 16 samples) of activations as MFMA B operand
   s16x8 hi, lo;
@@ -292,9 +306,9 @@ __device__ __forceinline__ float from_h(short b) {
   return (float)__builtin_bit_cast(__bf16, b);
 }
 // plain C++ form of the high / low split (every mode); fp16 x3: low part scaled by 2^11 (mlp_layout.hpp)
-template <bool F16, bool X3>
+template <bool F16, bool X3, bool LS = (F16 && X3)>
 __device__ __forceinline__ void split_store_cpp(const float v[8], Frag& f) {
-  constexpr float K = (F16 && X3) ? kLoScaleF16 : 1.0f;
+  constexpr float K = LS ? kLoScaleF16 : 1.0f;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const short h = to_h<F16>(v[j]);
@@ -306,10 +320,13 @@ __device__ __forceinline__ void split_store_cpp(const float v[8], Frag& f) {
 // The split the epilogues use.  NOTE (fp16 x3, asm form): the inputs must be results of VALU instructions the compiler
 // knows (the epilogue's merge / ReLU), never MFMA accumulators read directly - hipcc pads the XDL-write -> VALU-read
 // wait states only for instructions it sees.
-template <bool F16, bool X3>
+template <bool F16, bool X3, bool LS = (F16 && X3)>
 __device__ __forceinline__ void split_store(const float v[8], Frag& f) {
-#ifdef FSN_ABL_OLDEPI
-  if constexpr (F16 && X3) {
+#ifndef FSN_SPLIT_CPP
+  if constexpr (F16 && X3 && !LS) {
+    // UNSCALED low parts (FSN_PREC_FP16X3U): packed convert + one mixed-precision fma per value, low = fp16(v -
+    // float(high)) with a single rounding - bit-identical to split_store_cpp (checked on 65,536 values incl. subnormals
+    // in round 2).  Three instructions per two values.
     typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
     u32x4 h, l;
 #pragma unroll
@@ -327,9 +344,7 @@ __device__ __forceinline__ void split_store(const float v[8], Frag& f) {
     f.lo = __builtin_bit_cast(s16x8, l);
     return;
   }
-#endif
-#ifndef FSN_SPLIT_CPP
-  if constexpr (F16 && X3) {
+  if constexpr (F16 && X3 && LS) {
     // fp16 high part and SCALED low part of a pair of values in five instructions: packed round-to-nearest convert;
     // r = v - float(high) as one mixed-precision fma each (fp32 result: exact, |r| <= 2^-11 |v|); low = fp16(2^11 r),
     // again as mixed fma so that the scale costs nothing.  Bit-identical to split_store_cpp (one rounding, in the
@@ -356,7 +371,7 @@ __device__ __forceinline__ void split_store(const float v[8], Frag& f) {
     return;
   }
 #endif
-  split_store_cpp<F16, X3>(v, f);
+  split_store_cpp<F16, X3, LS>(v, f);
 }
 
 // Range guard of the fp16 modes.  range_track: running packed maximum of the |high part| bit patterns a lane has
@@ -391,13 +406,18 @@ struct RangeState {
   uint32_t small;  // wave-uniform: some layer's scale was below kSmallBits
 };
 
-template <bool SMALL>
+// FSN_PREC_FP16X3U: the low parts are unscaled, i.e. fp16 subnormals (fixed 2^-24 resolution) for |v| < 2^-3; the scaled
+// network keeps a layer's largest activation at 2^4 .. 2^10 (calibration target 2^10), so a wavefront whose layer
+// maximum is below 2^-4 says that the layer's scale no longer fits the data: reported like the other modes' low end.
+constexpr uint32_t kSmallBitsU = 0x2c00u;  // fp16 bit pattern of 2^-4
+
+template <bool SMALL, uint32_t BITS = kSmallBits>
 __device__ __forceinline__ void range_layer_end(RangeState& r) {
   asm("v_pk_max_u16 %0, %0, %1" : "+v"(r.fall) : "v"(r.fmax));
   if constexpr (SMALL) {
     const uint32_t lo = r.fmax & 0xffffu, hi = r.fmax >> 16;
     const uint32_t m = lo > hi ? lo : hi;
-    const int any_big = __builtin_amdgcn_readfirstlane((int)__any(m >= kSmallBits));
+    const int any_big = __builtin_amdgcn_readfirstlane((int)__any(m >= BITS));
     const int any_nz = __builtin_amdgcn_readfirstlane((int)__any(m != 0u));
     if (!any_big && any_nz) r.small = 1u;
   }
@@ -464,7 +484,7 @@ __device__ __forceinline__ void sincos_f32(float a, float& s_out, float& c_out) 
 // four lanes g = lane>>4 of a sample share the NKS*32 slots).
 // `save` (training forward only, else null): this lane's column of the encoding's packed T-layout buffer; slot
 // (k-step ks, element j) is row 32 ks + 8 g + j, i.e. B-operand order (train_fused.hip).
-template <int NKS, bool F16, bool X3, bool SAVE = false>
+template <int NKS, bool F16, bool X3, bool SAVE = false, bool LS = (F16 && X3)>
 __device__ __forceinline__ void encode(float x0, float x1, float x2, int n_freqs, const float* __restrict__ freqs,
                                        const float* __restrict__ mask, int g, Frag (&out)[NKS], uint32_t* save = nullptr) {
   constexpr int SLOTS = 8 * NKS;
@@ -500,7 +520,7 @@ __device__ __forceinline__ void encode(float x0, float x1, float x2, int n_freqs
   }
   if (g == 3) v[SLOTS - 2] = x2 * mask[2];
 #pragma unroll
-  for (int k = 0; k < NKS; ++k) split_store<F16, X3>(&v[8 * k], out[k]);
+  for (int k = 0; k < NKS; ++k) split_store<F16, X3, LS>(&v[8 * k], out[k]);
   if constexpr (SAVE) {
     // packed T-layout (train_fused.hip): slots (k, 2i), (k, 2i+1) are rows 32k + 8g + 2i, +1 = pair-row 16k + 4g + i;
     // `save` = this lane's sample at pair-row 4g (t_layout_off); x3: the two parts of a pair as one 8-byte store
@@ -562,8 +582,9 @@ __device__ __forceinline__ void unit_mfma_r(const AFrag& a, const Frag& b, f32x4
   constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
   acc = mfma16<F16>(a.hi, b.hi, acc);
   if (X3) {
-    if (PREC != 6) cor = mfma16<F16>(a.lo, b.hi, cor);  // (fp16x2: the weights' low parts are dropped)
-    cor = mfma16<F16>(a.hi, b.lo, cor);
+    f32x4& c = prec_one_acc(PREC) ? acc : cor;  // (FSN_PREC_FP16X3U: everything into the main tile)
+    if (PREC != 6) c = mfma16<F16>(a.lo, b.hi, c);  // (fp16x2: the weights' low parts are dropped)
+    c = mfma16<F16>(a.hi, b.lo, c);
   }
 }
 
@@ -611,11 +632,12 @@ __device__ __forceinline__ void unit_mfma(const char* ubase, const Frag& b, f32x
   const s16x8 ah = *reinterpret_cast<const s16x8*>(ubase);
   acc = mfma16<F16>(ah, b.hi, acc);
   if (X3) {
+    f32x4& c = prec_one_acc(PREC) ? acc : cor;
     if (PREC != 6) {
       const s16x8 al = *reinterpret_cast<const s16x8*>(ubase + 1024);
-      cor = mfma16<F16>(al, b.hi, cor);
+      c = mfma16<F16>(al, b.hi, c);
     }
-    cor = mfma16<F16>(ah, b.lo, cor);
+    c = mfma16<F16>(ah, b.lo, c);
   }
 }
 
@@ -641,7 +663,7 @@ template <int PREC, int NP_OUT, int EPI, int NOUT, class HK>
 __device__ __forceinline__ void pair_epilogue(const NetDev& net, int tp, const f32x4& acc0, const f32x4& acc1,
                                               const f32x4& cor0, const f32x4& cor1, Frag (&out)[NOUT], Heads& heads,
                                               int g, HK& hk) {
-  constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
+  constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0, LS = prec_lo_scaled_k(PREC);
 #if defined(FSN_PRIO) && FSN_PRIO == 1
     __builtin_amdgcn_s_setprio(0);
 #elif defined(FSN_PRIO) && FSN_PRIO == 2
@@ -650,11 +672,7 @@ __device__ __forceinline__ void pair_epilogue(const NetDev& net, int tp, const f
     __builtin_amdgcn_s_setprio(2);
 #endif
     float v[8];
-#ifdef FSN_ABL_OLDEPI  // timing experiment: rounds 1-2's epilogue (no merge, three-instruction split)
-    if constexpr (false) {
-#else
-    if constexpr (X3) {
-#endif
+    if constexpr (X3 && !prec_one_acc(PREC)) {
       // value = main + 2^-11 x corrections (fp16 modes: exact power-of-two unscaling inside the fma); bf16: scale 1
       constexpr float IK = F16 ? 1.0f / kLoScaleF16 : 1.0f;
 #ifndef FSN_EPI_PK_FMA
@@ -735,7 +753,10 @@ __device__ __forceinline__ void pair_epilogue(const NetDev& net, int tp, const f
       // states only for instructions it knows; found as 1e-3 gradient errors in the backward chain).  In the x3
       // modes v[] comes out of the merge fma above, a compiler-visible VALU instruction; the single-pass modes'
       // split is plain C++.
-      split_store<F16, X3>(v, o);
+      // (FSN_PREC_FP16X3U has no merge: where the epilogue has no ReLU either - the connection layer - v[] ARE the
+      // accumulators, and the asm split must not read them: the C++ form there)
+      if constexpr (prec_one_acc(PREC) && (EPI == EPI_CVT || EPI == EPI_NONE)) split_store_cpp<F16, X3, LS>(v, o);
+      else split_store<F16, X3, LS>(v, o);
       if constexpr (F16) range_track<EPI == EPI_CVT || EPI == EPI_NONE>(heads.rs.fmax, o.hi);
 #endif
       if (X3) asm volatile("" : "+v"(o.hi), "+v"(o.lo));
@@ -748,7 +769,7 @@ __device__ __forceinline__ void pair_epilogue(const NetDev& net, int tp, const f
         hk.template store<X3>(tp, out[tp < NOUT ? tp : 0]);
       } else {
         Frag t;
-        split_store_cpp<F16, X3>(v, t);
+        split_store_cpp<F16, X3, LS>(v, t);
         hk.template store<X3>(tp, t);
       }
     }
@@ -781,13 +802,18 @@ struct AccSets {
   f32x4 e0, e1, o0, o1, c0, c1;
 };
 
-#define FSN_KLOOP_PIN                                                                                              \
+#define FSN_KLOOP_PIN_X3                                                                                           \
   "+{v[240:243]}"(acc.e0), "+{v[244:247]}"(acc.e1), "+{v[248:251]}"(acc.o0), "+{v[252:255]}"(acc.o1),              \
       "=&{v[232:235]}"(acc.c0), "=&{v[236:239]}"(acc.c1)
+#define FSN_KLOOP_PIN_X2 FSN_KLOOP_PIN_X3
+// X3S (FSN_PREC_FP16X3U): no correction set - v[232:239] stay with the register allocator
+#define FSN_KLOOP_PIN_X3S \
+  "+{v[240:243]}"(acc.e0), "+{v[244:247]}"(acc.e1), "+{v[248:251]}"(acc.o0), "+{v[252:255]}"(acc.o1)
 #define FSN_KLOOP_SETS_X3                                                                                        \
   [s0h] "+v"(s0.hi), [s0l] "+v"(s0.lo), [s1h] "+v"(s1.hi), [s1l] "+v"(s1.lo), [s2h] "+v"(s2.hi), [s2l] "+v"(s2.lo), \
       [keep] "=&s"(keep)
 #define FSN_KLOOP_SETS_X2 [s0h] "+v"(s0.hi), [s1h] "+v"(s1.hi), [s2h] "+v"(s2.hi), [keep] "=&s"(keep)
+#define FSN_KLOOP_SETS_X3S FSN_KLOOP_SETS_X3
 #define FSN_B(k) bsel<k, KS_ACT, KS_ENC>(act, enc)
 #define FSN_KLOOP_INS                                                                                            \
   [b0h] "v"(FSN_B(0).hi), [b0l] "v"(FSN_B(0).lo), [b1h] "v"(FSN_B(1).hi), [b1l] "v"(FSN_B(1).lo),                \
@@ -810,9 +836,9 @@ struct AccSets {
     constexpr int EV = FSN_KLOOP_##NU_##_##OFF_##_EVENTS, NP = FSN_KLOOP_##NU_##_##OFF_##_PHASES;               \
     kloop_plan<EV, NP>(st, a, mv, gb);                                                                          \
     if constexpr (PAR == 0)                                                                                     \
-      FSN_KLOOP_EMIT(FSN_KLOOP_##MODE##_##NU_##_##OFF_##_N0, FSN_KLOOP_PIN FSN_COMMA FSN_KLOOP_SETS_##MODE);    \
+      FSN_KLOOP_EMIT(FSN_KLOOP_##MODE##_##NU_##_##OFF_##_N0, FSN_KLOOP_PIN_##MODE FSN_COMMA FSN_KLOOP_SETS_##MODE); \
     else                                                                                                        \
-      FSN_KLOOP_EMIT(FSN_KLOOP_##MODE##_##NU_##_##OFF_##_N1, FSN_KLOOP_PIN FSN_COMMA FSN_KLOOP_SETS_##MODE);    \
+      FSN_KLOOP_EMIT(FSN_KLOOP_##MODE##_##NU_##_##OFF_##_N1, FSN_KLOOP_PIN_##MODE FSN_COMMA FSN_KLOOP_SETS_##MODE); \
     st.opened(EV);                                                                                              \
   }
 #define FSN_COMMA ,
@@ -843,14 +869,25 @@ __device__ __forceinline__ const Frag& bsel(const Frag (&act)[NACT], const Frag 
 // in set E (PAR 0) or O (PAR 1), which holds its bias on entry; the other set receives the next pair's bias (abn =
 // its LDS address); the correction sums are written to set C from zero.
 // s0,s1: A sets holding units 0,1 on entry; on exit units NU, NU+1 sit in sets (NU % 3), ((NU+1) % 3) of (s0,s1,s2).
-template <bool F16, bool TWO, int KS_ACT, int KS_ENC, int OFF, int PAR, int NACT, int NENC>
+// MODE: 0 = X3 (correction set), 1 = X2, 2 = X3S (one accumulator)
+template <bool F16, int MODE, int KS_ACT, int KS_ENC, int OFF, int PAR, int NACT, int NENC>
 __device__ __forceinline__ void kloop_block(WStream& st, const Frag (&act)[NACT], const Frag (&enc)[NENC],
                                             AccSets& acc, uint32_t abn, AFrag& s0, AFrag& s1, AFrag& s2) {
   constexpr int NU = 2 * (KS_ACT + KS_ENC);
   uint32_t a[4], mv[3], keep;
   uint64_t gb[3];
   const uint32_t voff = ((FSN_TIDX >> 6) ^ FSN_LOADER_XOR) * (kGldsPerWave * 1024) + (FSN_TIDX & 63) * 16;
-  if constexpr (!TWO) {
+  if constexpr (MODE == 2) {
+    FSN_KLOOP_CASE(X3S, 16, 0)
+    FSN_KLOOP_CASE(X3S, 20, 0)
+    FSN_KLOOP_CASE(X3S, 20, 4)
+    FSN_KLOOP_CASE(X3S, 18, 0)
+    FSN_KLOOP_CASE(X3S, 18, 2)
+    FSN_KLOOP_CASE(X3S, 18, 4)
+    FSN_KLOOP_CASE(X3S, 18, 6)
+    FSN_KLOOP_CASE(X3S, 4, 0)
+    FSN_KLOOP_CASE(X3S, 4, 4)
+  } else if constexpr (MODE == 0) {
     FSN_KLOOP_CASE(X3, 16, 0)
     FSN_KLOOP_CASE(X3, 20, 0)
     FSN_KLOOP_CASE(X3, 20, 4)
@@ -891,6 +928,7 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
   // forward passes (bias-initialised accumulators; the backward chain starts from zero) also check the layer's scale
   constexpr bool kConverts = EPI == EPI_RELU_CVT || EPI == EPI_CVT || EPI == EPI_LAST_FULL;
   constexpr bool kCheckSmall = X3 && !HK::kZeroInit;
+  constexpr uint32_t kSmallThr = prec_one_acc(PREC) ? kSmallBitsU : kSmallBits;
   static_assert(kLead >= 2, "the A-operand prefetch distance (one k-step = two units) must not exceed the phase lead");
   constexpr bool PREFETCH = !X3;
 #ifdef FSN_X3_PF1
@@ -932,7 +970,7 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
       const uint64_t ts0 = __builtin_amdgcn_s_memtime();
 #endif
       const uint32_t abn = bias_lds + 128u * (tp + 1 < NP_OUT ? tp + 1 : tp);  // (last pair: a harmless reload)
-      kloop_block<F16, PREC == 6, KS_ACT, KS_ENC, OFF, PAR>(st, act, enc, acc, abn, ring.cur[R0], ring.cur[(R0 + 1) % NS],
+      kloop_block<F16, PREC == 6 ? 1 : (prec_one_acc(PREC) ? 2 : 0), KS_ACT, KS_ENC, OFF, PAR>(st, act, enc, acc, abn, ring.cur[R0], ring.cur[(R0 + 1) % NS],
                                                             ring.cur[(R0 + 2) % NS]);
 #ifdef FSN_STAMP
       const uint64_t ts1 = __builtin_amdgcn_s_memtime();
@@ -964,7 +1002,7 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
     }
     if constexpr (F16 && kConverts) {
       if constexpr (HK::kLayerEnd) hk.layer_end(heads.rs.fmax);
-      range_layer_end<kCheckSmall>(heads.rs);
+      range_layer_end<kCheckSmall, kSmallThr>(heads.rs);
     }
     return;
   }
@@ -1046,7 +1084,7 @@ __device__ __forceinline__ void gemm_layer(WStream& st, const NetDev& net, int a
   }
   if constexpr (F16 && kConverts) {
     if constexpr (HK::kLayerEnd) hk.layer_end(heads.rs.fmax);
-    range_layer_end<kCheckSmall>(heads.rs);
+    range_layer_end<kCheckSmall, kSmallThr>(heads.rs);
   }
 }
 
@@ -1228,13 +1266,14 @@ struct NoSave {
   __device__ __forceinline__ Hook branch() const { return {}; }
   __device__ __forceinline__ uint32_t* enc_pos(int) const { return nullptr; }
   __device__ __forceinline__ uint32_t* enc_dir(int) const { return nullptr; }
+  __device__ __forceinline__ void layer_done(int, Hook&) const {}  // after GEMM l (kernel order) of a tile
 };
 
 template <int NT, int PREC, bool FULL, class Src, class SV>
 __device__ __forceinline__ void mlp_tile(WStream& st, const NetDev& net, const Src& src, ARing& ring, float& sigma,
                                          float (&rgb)[3], const SV& sv) {
   constexpr int NA = NT;  // k-steps of 32 across the hidden width
-  constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0;
+  constexpr bool F16 = PREC >= 2, X3 = (PREC & 1) == 0, LS = prec_lo_scaled_k(PREC);
   const int g = (FSN_TIDX >> 4) & 3;
   constexpr int D = 32 * NT;
   const int L = net.n_layers;
@@ -1246,9 +1285,10 @@ __device__ __forceinline__ void mlp_tile(WStream& st, const NetDev& net, const S
     Frag pe[kKsPos];
     float px, py, pz;
     src.pos(px, py, pz);
-    encode<kKsPos, F16, X3, SV::kSave>(px, py, pz, net.n_freqs_pos, misc + 4, net.pos_mask, g, pe, sv.enc_pos(g));
+    encode<kKsPos, F16, X3, SV::kSave, LS>(px, py, pz, net.n_freqs_pos, misc + 4, net.pos_mask, g, pe, sv.enc_pos(g));
     typename SV::Hook hk = sv.hidden(0);
     gemm_layer<PREC, NT, 0, kKsPos, EPI_RELU_CVT>(st, net, 0, none, pe, A, heads, ring, g, hk);
+    sv.layer_done(0, hk);
   }
   // A wide (skip) layer re-encodes the position instead of keeping the 16 registers of `pe` alive across the layers
   // in between (same function of the same inputs: identical values; fused kernel: 360 -> 256 B of scratch, +1.5 %).
@@ -1259,10 +1299,11 @@ __device__ __forceinline__ void mlp_tile(WStream& st, const NetDev& net, const S
       Frag pe2[kKsPos];                                                                       \
       float qx, qy, qz;                                                                       \
       src.pos(qx, qy, qz);                                                                    \
-      encode<kKsPos, F16, X3, false>(qx, qy, qz, net.n_freqs_pos, misc + 4, net.pos_mask, g, pe2); \
+      encode<kKsPos, F16, X3, false, LS>(qx, qy, qz, net.n_freqs_pos, misc + 4, net.pos_mask, g, pe2); \
       gemm_layer<PREC, NT, NA, kKsPos, EPI>(st, net, (LIDX)*D, IN, pe2, OUT, heads, ring, g, hk); \
     } else                                                                                    \
       gemm_layer<PREC, NT, NA, 0, EPI>(st, net, (LIDX)*D, IN, none, OUT, heads, ring, g, hk);     \
+    sv.layer_done(LIDX, hk);                                                                  \
   } while (0)
   for (int l = 1; l <= L - 2; l += 2) {
     FSN_HIDDEN(EPI_RELU_CVT, A, B, l);
@@ -1287,14 +1328,16 @@ __device__ __forceinline__ void mlp_tile(WStream& st, const NetDev& net, const S
     {
       typename SV::Hook hk = sv.hidden(L);
       gemm_layer<PREC, NT, NA, 0, EPI_CVT>(st, net, L * D, B, none, A, heads, ring, g, hk);
+      sv.layer_done(L, hk);
     }
     Frag de[kKsDir];
     float dx, dy, dz;
     src.dir(dx, dy, dz);
-    encode<kKsDir, F16, X3, SV::kSave>(dx, dy, dz, net.n_freqs_dir, misc + 20, net.dir_mask, g, de, sv.enc_dir(g));
+    encode<kKsDir, F16, X3, SV::kSave, LS>(dx, dy, dz, net.n_freqs_dir, misc + 20, net.dir_mask, g, de, sv.enc_dir(g));
     {
       typename SV::Hook hk = sv.branch();
       gemm_layer<PREC, NT / 2, NA, kKsDir, EPI_RGB>(st, net, (L + 1) * D, A, de, B, heads, ring, g, hk);
+      sv.layer_done(L + 1, hk);
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {

@@ -42,7 +42,12 @@ FSN_HD bool prec_is_f16(int prec) { return prec >= 2; }
 // are summed in their own accumulator and folded in as 2^-11 * corr by the epilogue.  bf16 has float32's exponent
 // range: scale 1.
 constexpr float kLoScaleF16 = 2048.0f;
-FSN_HD float lo_scale(int prec) { return (prec_is_f16(prec) && prec_is_x3(prec)) ? kLoScaleF16 : 1.0f; }
+// FSN_PREC_FP16X3U (round 4): low parts UNSCALED, all three products of a unit in one accumulator - float32-grade because
+// per-layer power-of-two scales folded into the packed weights (mlp_pack.hpp, PackArgs::sc_*) keep every layer's
+// activations at 2^4 .. 2^10, where an activation's unscaled low part is a normal fp16 number or negligible against the
+// layer's scale.
+FSN_HD bool prec_lo_scaled(int prec) { return prec == FSN_PREC_FP16X3 || prec == FSN_PREC_FP16X2; }
+FSN_HD float lo_scale(int prec) { return prec_lo_scaled(prec) ? kLoScaleF16 : 1.0f; }
 FSN_HD int unit_bytes(int prec) { return prec_is_x3(prec) ? 2048 : 1024; }
 FSN_HD int units_per_phase(int prec) { return kPhaseBytes / unit_bytes(prec); }
 
@@ -149,7 +154,7 @@ FSN_HD float half_to_f32(uint16_t h, bool f16) { return f16 ? f16_to_f32(h) : bf
 // Fills `G` from the descriptor; returns 0 or an FSN_E_* code (message via set_error on host).
 inline int build_geom(const fsn_mlp_desc& d, int prec, NetGeom& G, const char** why) {
   *why = "";
-  if (prec < 0 || (prec > 3 && prec != FSN_PREC_FP16X2)) { *why = "unknown precision mode"; return FSN_E_INVALID; }
+  if (prec < 0 || (prec > FSN_PREC_FP16X3U && prec != FSN_PREC_FP16X2)) { *why = "unknown precision mode"; return FSN_E_INVALID; }
   if (d.d_hidden != 256 && d.d_hidden != 128) { *why = "d_hidden must be 128 or 256"; return FSN_E_UNSUPPORTED; }
   if (d.n_layers < 2 || d.n_layers > kMaxLayers) { *why = "n_layers must be in [2,16]"; return FSN_E_UNSUPPORTED; }
   if (d.n_freqs_pos < 0 || d.n_freqs_pos > 10) { *why = "n_freqs (position) must be <= 10"; return FSN_E_UNSUPPORTED; }

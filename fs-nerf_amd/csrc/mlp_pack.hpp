@@ -14,7 +14,33 @@ struct PackArgs {
   uint32_t skip_mask;
   int32_t n_freqs_pos, n_freqs_dir;
   float freqs_pos[16], freqs_dir[16];
+  // per-layer activation scales folded into the packed network (fsn_mlp_pack_scaled; all 1 = the plain network): GEMM g
+  // produces 2^exps[g] x the reference's activations.  Factors on GEMM g's weight columns fed by activations / by an
+  // encoding, on its bias, and on the two float32 heads.
+  int32_t exps[kMaxLayers + 2];
+  float sc_act[kMaxLayers + 2], sc_enc[kMaxLayers + 2], sc_bias[kMaxLayers + 2], sc_sigma, sc_rgb;
 };
+
+FSN_HD float pow2f(int e) {  // 2^e as float32, |e| <= 126
+  union { float f; uint32_t u; } v;
+  v.u = (uint32_t)(e + 127) << 23;
+  return v.f;
+}
+
+// exps: n_layers + 2 exponents in kernel GEMM order (hidden 0..L-1, connection, branch) or null (all zero)
+inline void fill_scales(PackArgs& a, const int32_t* exps) {
+  const int L = a.n_layers;
+  for (int g = 0; g < L + 2; ++g) a.exps[g] = exps ? exps[g] : 0;
+  for (int g = L + 2; g < kMaxLayers + 2; ++g) a.exps[g] = 0;
+  for (int g = 0; g < L + 2; ++g) {
+    const int prev = g == 0 ? 0 : (g <= L ? a.exps[g == L ? L - 1 : g - 1] : a.exps[L]);  // connection reads layer L-1, branch the connection
+    a.sc_act[g] = pow2f(a.exps[g] - prev);
+    a.sc_enc[g] = pow2f(a.exps[g]);
+    a.sc_bias[g] = pow2f(a.exps[g]);
+  }
+  a.sc_sigma = pow2f(-a.exps[L - 1]);
+  a.sc_rgb = pow2f(-a.exps[L + 1]);
+}
 
 // weight index (state_dict order) of GEMM g (kernel order: hidden 0..L-1, connection, branch)
 FSN_HD int gemm_to_sd(int g, int L) { return g < L ? g : g + 1; }  // skips "sigma" at index L
@@ -41,7 +67,7 @@ FSN_HD void pack_piece(const PackArgs& a, int64_t piece, uint16_t out8[8]) {
   for (int j = 0; j < 8; ++j) {
     const int col = unit_src_col(Lg, ks, grp, j);
     if (col < 0) continue;
-    const float w = W[(int64_t)row * Lg.ld + col];
+    const float w = W[(int64_t)row * Lg.ld + col] * (ks < Lg.ks_act ? a.sc_act[g] : a.sc_enc[g]);  // (exact: powers of two)
     const bool f16 = prec_is_f16(a.prec);
     const uint16_t hi = half_rne(w, f16);
     out8[j] = part == 0 ? hi : half_rne((w - half_to_f32(hi, f16)) * lo_scale(a.prec), f16);
@@ -52,13 +78,13 @@ FSN_HD void pack_piece(const PackArgs& a, int64_t piece, uint16_t out8[8]) {
 FSN_HD float aux_value(const PackArgs& a, int i) {
   const int D = a.d_hidden, L = a.n_layers;
   const int blk = i / D, off = i - blk * D;
-  if (blk < L) return a.b[blk][off];                          // hidden biases
-  if (blk == L) return a.b[L + 1][off];                       // connection bias
-  if (blk == L + 1) return off < D / 2 ? a.b[L + 2][off] : 0.f;  // branch bias
-  if (blk == L + 2) return a.W[L][off];                       // sigma.weight [1,D]
-  if (blk == L + 3 || blk == L + 4) {                         // rgb.weight [3,D/2]
+  if (blk < L) return a.b[blk][off] * a.sc_bias[blk];                          // hidden biases
+  if (blk == L) return a.b[L + 1][off] * a.sc_bias[L];                         // connection bias
+  if (blk == L + 1) return off < D / 2 ? a.b[L + 2][off] * a.sc_bias[L + 1] : 0.f;  // branch bias
+  if (blk == L + 2) return a.W[L][off] * a.sc_sigma;                           // sigma.weight [1,D]
+  if (blk == L + 3 || blk == L + 4) {                                          // rgb.weight [3,D/2]
     const int k = i - (L + 3) * D;
-    return k < 3 * (D / 2) ? a.W[L + 3][k] : 0.f;
+    return k < 3 * (D / 2) ? a.W[L + 3][k] * a.sc_rgb : 0.f;
   }
   const int m = i - (L + 5) * D;
   if (m == 0) return a.b[L][0];                 // sigma.bias
@@ -70,7 +96,8 @@ FSN_HD float aux_value(const PackArgs& a, int i) {
 
 FSN_HD void header_words(const PackArgs& a, uint32_t hw[64]) {
   for (int i = 0; i < 64; ++i) hw[i] = 0;
-  hw[0] = kBlobMagic; hw[1] = 2;  // layout version 2: scaled low parts (mlp_layout.hpp, lo_scale)
+  hw[0] = kBlobMagic; hw[1] = 3;  // layout version 3: low parts scaled by lo_scale(prec) (mlp_layout.hpp); per-layer
+  for (int g = 0; g < a.n_layers + 2; ++g) hw[16 + g] = (uint32_t)a.exps[g];  // activation exponents at words 16..
   hw[2] = (uint32_t)a.prec; hw[3] = (uint32_t)a.n_layers;
   hw[4] = (uint32_t)a.d_hidden; hw[5] = a.skip_mask; hw[6] = (uint32_t)a.n_freqs_pos;
   hw[7] = (uint32_t)a.n_freqs_dir; hw[8] = (uint32_t)a.G.units_total; hw[9] = (uint32_t)a.G.nph_full;
@@ -81,7 +108,7 @@ FSN_HD void header_words(const PackArgs& a, uint32_t hw[64]) {
 
 // Fills `a` from the descriptor and the weight / bias pointer tables; returns 0 or an FSN_E_* code and a message.
 inline int fill_pack_args_raw(const fsn_mlp_desc* d, int prec, const float* const* W, const float* const* b, PackArgs& a,
-                              const char** why) {
+                              const char** why, const int32_t* exps = nullptr) {
   *why = "";
   if (!d || !W || !b) { *why = "null pointer"; return FSN_E_INVALID; }
   const int rc = build_geom(*d, prec, a.G, why);
@@ -94,14 +121,18 @@ inline int fill_pack_args_raw(const fsn_mlp_desc* d, int prec, const float* cons
   a.n_layers = d->n_layers; a.d_hidden = d->d_hidden; a.prec = prec; a.skip_mask = d->skip_mask;
   a.n_freqs_pos = d->n_freqs_pos; a.n_freqs_dir = d->n_freqs_dir;
   for (int i = 0; i < 16; ++i) { a.freqs_pos[i] = d->freqs_pos[i]; a.freqs_dir[i] = d->freqs_dir[i]; }
+  if (exps)
+    for (int g = 0; g < d->n_layers + 2; ++g)
+      if (exps[g] < -60 || exps[g] > 60) { *why = "layer exponent outside [-60, 60]"; return FSN_E_INVALID; }
+  fill_scales(a, exps);
   return FSN_OK;
 }
 
 // The whole blob on the host (format tests; the sanitizer build runs exactly this).
 inline int pack_blob_host(const fsn_mlp_desc* d, int prec, const float* const* W, const float* const* b, void* blob_host,
-                          const char** why) {
+                          const char** why, const int32_t* exps = nullptr) {
   PackArgs a;
-  const int rc = fill_pack_args_raw(d, prec, W, b, a, why);
+  const int rc = fill_pack_args_raw(d, prec, W, b, a, why, exps);
   if (rc != FSN_OK) return rc;
   char* blob = static_cast<char*>(blob_host);
   for (int64_t i = 0; i < a.G.total_bytes; ++i) blob[i] = 0;

@@ -21,6 +21,7 @@
 #if FSN_LAG
 #define FSN_NSLOT 6
 #endif
+#define FSN_BF16X3_ONEACC 1  // inference: bf16x3 accumulates its three products in one tile (mlp_dev.hpp)
 #include "mlp_dev.hpp"
 #include "ray_dev.hpp"
 
@@ -465,6 +466,7 @@ extern "C" int fsn_render_rays_fused(const fsn_mlp_desc* desc, int prec, const v
   if (cus <= 0) return FSN_E_HIP;
   hipStream_t s = as_stream(stream);
   if (prec == FSN_PREC_FP16X2) return desc->d_hidden == 256 ? launch_render<8, 6>(k, cus, s) : launch_render<4, 6>(k, cus, s);
+  if (prec == FSN_PREC_FP16X3U) return desc->d_hidden == 256 ? launch_render<8, 4>(k, cus, s) : launch_render<4, 4>(k, cus, s);
   const int key = (desc->d_hidden == 256 ? 4 : 0) + prec;
   switch (key) {
     case 0: return launch_render<4, 0>(k, cus, s);

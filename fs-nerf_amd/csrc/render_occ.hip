@@ -15,6 +15,7 @@
 // the unfused path's (march -> k_mlp_fwd -> k_visibility -> k_mlp_fwd -> k_composite_packed).
 #include "common.hpp"
 #define FSN_KLOOP_ASM
+#define FSN_BF16X3_ONEACC 1  // inference: bf16x3 accumulates its three products in one tile (mlp_dev.hpp)
 #include "mlp_dev.hpp"
 #include "occ_dev.hpp"
 #include "ray_dev.hpp"
@@ -333,7 +334,7 @@ extern "C" int fsn_render_rays_occgrid(const fsn_mlp_desc* desc, int prec, const
   FSN_REQUIRE(desc && args, FSN_E_INVALID, "fsn_render_rays_occgrid: null pointer");
   const fsn_occ_render_args& a = *args;
   FSN_REQUIRE(a.R >= 0 && a.step > 0.f && a.max_steps > 0, FSN_E_INVALID, "fsn_render_rays_occgrid: bad sizes");
-  FSN_REQUIRE(prec >= 0 && prec <= FSN_PREC_FP16, FSN_E_UNSUPPORTED, "fsn_render_rays_occgrid: precision mode %d", prec);
+  FSN_REQUIRE(prec >= 0 && prec <= FSN_PREC_FP16X3U, FSN_E_UNSUPPORTED, "fsn_render_rays_occgrid: precision mode %d", prec);
   NetGeom G;
   const char* why;
   int rc = build_geom(*desc, prec, G, &why);
@@ -376,6 +377,7 @@ extern "C" int fsn_render_rays_occgrid(const fsn_mlp_desc* desc, int prec, const
   if (cus <= 0) return FSN_E_HIP;
   hipStream_t s = as_stream(stream);
   FSN_HIP(hipMemsetAsync(a.work_counter, 0, sizeof(unsigned long long), s));
+  if (prec == FSN_PREC_FP16X3U) return desc->d_hidden == 256 ? launch_occ<8, 4>(k, cus, s) : launch_occ<4, 4>(k, cus, s);
   const int key = (desc->d_hidden == 256 ? 4 : 0) + prec;
   switch (key) {
     case 0: return launch_occ<4, 0>(k, cus, s);

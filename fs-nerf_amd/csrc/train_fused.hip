@@ -202,6 +202,7 @@ struct FwdSaver {
   int branch_pairs;  // output pairs of the branch layer (D / 64)
   __device__ __forceinline__ uint32_t* enc_pos(int) const { return pe; }
   __device__ __forceinline__ uint32_t* enc_dir(int) const { return de; }
+  __device__ __forceinline__ void layer_done(int, Hook&) const {}
 };
 
 struct TrainFwdArgs {

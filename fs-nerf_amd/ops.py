@@ -255,7 +255,8 @@ def describe_flags(bits: int) -> str:
     if bits & L.FSN_STATUS_FP16_RANGE:
         what.append("values reached the top of the fp16 range (|v| >= 65504)")
     if bits & L.FSN_STATUS_FP16_SMALL:
-        what.append("a layer's activations were all below 2^-14 (below the split's float32-grade envelope)")
+        what.append("a layer's activations were all below 2^-14 (below the split's float32-grade envelope; scaled "
+                    "inference: a wavefront's layer maximum below 2^-4)")
     return " and ".join(what) if what else "inside the envelope"
 
 
@@ -297,18 +298,41 @@ class PackedMLP:
             L.check(int(nbytes), "fsn_mlp_blob_bytes")
         self.blob = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
 
-    def pack(self, weights: Sequence[Tensor], biases: Sequence[Tensor]) -> "PackedMLP":
+    def pack(self, weights: Sequence[Tensor], biases: Sequence[Tensor], exps: Optional[Sequence[int]] = None) -> "PackedMLP":
+        """`exps`: n_layers + 2 per-GEMM activation exponents (fsn_mlp_pack_scaled: the blob then holds the network whose
+        GEMM g produces 2^exps[g] times the reference's activations, heads unscaled accordingly), or None."""
         n = self.desc.n_layers + 4
         assert len(weights) == n and len(biases) == n
         ws = [_f32(w.detach(), "weight") for w in weights]
         bs = [_f32(b.detach(), "bias") for b in biases]
         Wp = (C.c_void_p * n)(*[w.data_ptr() for w in ws])
         Bp = (C.c_void_p * n)(*[b.data_ptr() for b in bs])
+        ex = None
+        if exps is not None:
+            assert len(exps) == self.desc.n_layers + 2
+            ex = (C.c_int32 * len(exps))(*[int(e) for e in exps])
+        self.exps = None if exps is None else tuple(int(e) for e in exps)
         with torch.cuda.device(self.blob.device):
-            L.check(L.lib().fsn_mlp_pack(C.byref(self.desc), self.prec, Wp, Bp, _p(self.blob), _stream()),
-                    "fsn_mlp_pack")
+            L.check(L.lib().fsn_mlp_pack_scaled(C.byref(self.desc), self.prec, Wp, Bp, ex, _p(self.blob), _stream()),
+                    "fsn_mlp_pack_scaled")
         self._keep = (ws, bs)  # alive until the stream work is queued behind later launches
         return self
+
+
+def mlp_layer_maxima(pm: PackedMLP, x: Tensor, dirs: Tensor, pos_mask: Optional[Tensor] = None,
+                     dir_mask: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    """Per-GEMM largest |activation| of NeRF.forward(x, dirs) over the probe samples (fsn_mlp_layer_maxima) ->
+    float32 [n_layers + 2] on the device, in the scale of the blob `pm`.  `out`: accumulate into an earlier result."""
+    x, d = _f32(x, "x").reshape(-1, 3), _f32(dirs, "dirs").reshape(-1, 3)
+    assert x.shape == d.shape
+    pmk = None if pos_mask is None else _f32(pos_mask, "pos_mask")
+    dmk = None if dir_mask is None else _f32(dir_mask, "dir_mask")
+    if out is None:
+        out = torch.zeros(pm.desc.n_layers + 2, device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        L.check(L.lib().fsn_mlp_layer_maxima(C.byref(pm.desc), pm.prec, _p(pm.blob), _p(x), _p(d), _p(pmk), _p(dmk),
+                                             x.shape[0], _p(out), _stream()), "fsn_mlp_layer_maxima")
+    return out
 
 
 def mlp_fwd(pm: PackedMLP, x: Tensor, dirs: Optional[Tensor] = None, pos_mask: Optional[Tensor] = None,

@@ -120,6 +120,77 @@ def rendering(t_starts: Tensor, t_ends: Tensor, ray_indices: Tensor, n_rays: int
     return colors, opacity, depth, ex
 
 
+def _probe_on_rays(rays_o, rays_d, camera, t_lo: float, t_hi: float, n_rays: int = 512, n_t: int = 32):
+    """Probe batch for NeRF.calibrate (per-layer activation scales of the fp16x3 inference path): positions o + d t on
+    an even subset of the call's rays (or of the camera's) at n_t depths across [t_lo, t_hi], with the rays' directions."""
+    if rays_o is None:
+        pose, H, W, focal, row0, nrows, dev = camera
+        rays_o, rays_d = ops.get_rays(pose, int(H), int(W), float(focal), dev, int(row0), int(nrows))
+    R, dev = rays_o.shape[0], rays_o.device
+    idx = torch.linspace(0, max(R - 1, 0), min(max(R, 1), n_rays), device=dev).long()
+    o, d = rays_o.reshape(-1, 3)[idx].float(), rays_d.reshape(-1, 3)[idx].float()
+    t = t_lo + (t_hi - t_lo) * (torch.arange(n_t, device=dev, dtype=torch.float32) + 0.5) / n_t
+    x = o[:, None, :] + d[:, None, :] * t[None, :, None]
+    return x.reshape(-1, 3), d[:, None, :].expand(-1, n_t, -1).reshape(-1, 3)
+
+
+def _probe_in_box(rays_o, rays_d, camera, aabb, n: int = 16384):
+    """Probe batch for the occupancy estimator's path: positions uniform in the grid's box (every sample the march
+    produces lies inside it), directions from an even subset of the call's rays."""
+    if rays_o is None:
+        pose, H, W, focal, row0, nrows, dev = camera
+        rays_o, rays_d = ops.get_rays(pose, int(H), int(W), float(focal), dev, int(row0), int(nrows))
+    dev = rays_d.device
+    R = rays_d.reshape(-1, 3).shape[0]
+    idx = torch.linspace(0, max(R - 1, 0), n, device=dev).long()
+    g = torch.Generator(device="cpu").manual_seed(0)
+    lo = torch.tensor([float(v) for v in aabb[:3]], device=dev)
+    hi = torch.tensor([float(v) for v in aabb[3:]], device=dev)
+    x = lo + (hi - lo) * torch.rand(n, 3, generator=g).to(dev)
+    return x, rays_d.reshape(-1, 3)[idx].float()
+
+
+def _run_guarded(nets, dev, launch, probe, what: str):
+    """`launch()` under the fp16 range guard for the NeRFs `nets` it evaluates (one precision mode for all of them): the
+    policy of NeRF._guarded - synchronous read-back and re-run after fall_back (re-calibration of the scaled fp16x3 path,
+    or bf16x3), or the deferred form."""
+    f16 = lambda m: m.fp16_family(m.PRECISIONS[m.precision])
+    guarded = [m for m in nets if m.range_check and f16(m)]
+
+    def fall_back(msg, bits, earlier=False):
+        for m in nets:  # the coarse and the fine pass run in one precision mode
+            if f16(m):
+                m.fall_back(msg, bits, probe, earlier_invalid=earlier)
+        modes = {m.infer_prec() for m in nets}
+        if len(modes) > 1:  # one net could re-calibrate, another had to give up: both continue in bf16x3
+            for m in nets:
+                if f16(m):
+                    m.act_scaling = False
+                    m.fall_back(msg, bits, scaled=False)
+
+    if guarded and all(m.range_check == "deferred" for m in guarded):
+        # batch rendering in small launches: no wait for the GPU per call.  The word of the PREVIOUS launch is looked
+        # at now (its asynchronous read-back has long landed); a raised flag re-calibrates / switches the models for this
+        # and all later calls and says that the previous call's outputs are not to be used.  ops.range_poll /
+        # render_frame's end of frame give the certain answer.
+        bits = ops.range_poll(dev)
+        if bits:
+            fall_back("an EARLIER render_rays call (deferred range check: its outputs are invalid)", bits, True)
+        out = launch()
+        if any(f16(m) for m in nets):
+            ops.range_post(dev)
+        return out
+    out = launch()
+    for _ in range(5):
+        bits = ops.range_flags(dev) if guarded else 0
+        if not bits:
+            break
+        fall_back(what, bits)
+        out = launch()
+        guarded = [m for m in nets if m.range_check and f16(m)]
+    return out
+
+
 def _fused_launch(rays_o, rays_d, camera, estimator, model, model_fine, train, bk, u, u_fine, want_extras):
     """ONE fused launch (ops.render_fused) for ray tensors or for a camera (rays generated in the launch), with the
     fp16 range guard: if the kernels report activations outside the fp16 range the call is repeated in bf16x3."""
@@ -136,38 +207,16 @@ def _fused_launch(rays_o, rays_d, camera, estimator, model, model_fine, train, b
     pm = fine._mask(fine.pos_mask, dev)
     dm = fine._mask(fine.dir_mask, dev)
 
+    probe = lambda: _probe_on_rays(rays_o, rays_d, camera, near, far)
+
     def launch():
         return ops.render_fused(
-            model.packed() if estimator.n_importance > 0 else None, fine.packed(), rays_o, rays_d,
+            model.packed(probe) if estimator.n_importance > 0 else None, fine.packed(probe), rays_o, rays_d,
             near=near, far=far, n_samples=estimator.n_samples, n_importance=estimator.n_importance,
             u=u, u_fine=u_fine, bkgd=(bk, bk, bk), pos_mask=pm, dir_mask=dm, want_extras=want_extras, camera=camera)
 
     nets = [m for m in {id(model): model, id(fine): fine}.values()]
-    guarded = [m for m in nets if m.range_check and m.fp16_family(m.PRECISIONS[m.precision])]
-
-    def fall_back(what, bits):
-        for m in nets:  # the coarse and the fine pass run in one precision mode
-            if m.fp16_family(m.PRECISIONS[m.precision]):
-                m.fall_back(what, bits)
-
-    if guarded and all(m.range_check == "deferred" for m in guarded):
-        # batch rendering in small launches: no wait for the GPU per call.  The word of the PREVIOUS launch is looked
-        # at now (its asynchronous read-back has long landed); a raised flag switches the models for this and all later
-        # calls and says that the previous call's outputs are not to be used.  ops.range_poll / render_frame's end
-        # of frame give the certain answer.
-        bits = ops.range_poll(dev)
-        if bits:
-            fall_back("an EARLIER render_rays call (deferred range check: its outputs are invalid)", bits)
-        out = launch()
-        if any(m.fp16_family(m.PRECISIONS[m.precision]) for m in nets):
-            ops.range_post(dev)
-        return out
-    out = launch()
-    bits = ops.range_flags(dev) if guarded else 0
-    if bits:
-        fall_back("render_rays", bits)
-        out = launch()
-    return out
+    return _run_guarded(nets, dev, launch, probe, "render_rays")
 
 
 # render_rays with gradients / extras: OccGridEstimator.sampling as one launch + one gather (ops.occ_sample_fused), for
@@ -198,28 +247,16 @@ def _fused_occ_launch(rays_o, rays_d, camera, estimator: OccGridEstimator, model
     u = torch.rand(R, device=dev, generator=estimator.generator) if train else None
     pm, dm = model._mask(model.pos_mask, dev), model._mask(model.dir_mask, dev)
 
+    probe = lambda: _probe_in_box(rays_o, rays_d, camera, estimator.aabb)
+
     def launch():
-        return ops.render_occ_fused(model.packed(), rays_o, rays_d, aabb=estimator.aabb, res=estimator.resolution,
+        return ops.render_occ_fused(model.packed(probe), rays_o, rays_d, aabb=estimator.aabb, res=estimator.resolution,
                                     levels=estimator.levels, bits=estimator.bits, near_plane=0.0, far_plane=1e10,
                                     step=render_step_size, max_steps=estimator.max_steps(render_step_size), u=u,
                                     early_stop_eps=1e-4, alpha_thre=0.0, bkgd=(bk, bk, bk), pos_mask=pm, dir_mask=dm,
                                     camera=camera, want_counts=want_counts)
 
-    guarded = model.range_check and model.fp16_family(model.PRECISIONS[model.precision])
-    if guarded and model.range_check == "deferred":
-        bits = ops.range_poll(dev)
-        if bits:
-            model.fall_back("an EARLIER render_rays call (deferred range check: its outputs are invalid)", bits)
-        out = launch()
-        if model.fp16_family(model.PRECISIONS[model.precision]):
-            ops.range_post(dev)
-        return out
-    out = launch()
-    bits = ops.range_flags(dev) if guarded else 0
-    if bits:
-        model.fall_back("render_rays", bits)
-        out = launch()
-    return out
+    return _run_guarded([model], dev, launch, probe, "render_rays")
 
 
 def render_rays(rays_o: Tensor, rays_d: Tensor, estimator, model: nn.Module, train: bool = False,
@@ -275,22 +312,21 @@ def render_rays(rays_o: Tensor, rays_d: Tensor, estimator, model: nn.Module, tra
             kw_s = dict(near=near_, far=far_, n_samples=estimator.n_samples, n_importance=estimator.n_importance, u=uu,
                         u_fine=uf, pos_mask=model._mask(model.pos_mask, dev_), dir_mask=model._mask(model.dir_mask, dev_))
             f16 = model.fp16_family(model.PRECISIONS[model.precision])
+            probe_s = lambda: _probe_on_rays(rays_o, rays_d, None, near_, far_)
             with torch.no_grad():
                 if needs_grad and f16 and model.range_check:
                     # training step: no host read-back between the sampler and the forward (it cost the step 0.2 ms of idle
                     # GPU).  The sampler reports into a word of its own, which joins the step's guard on the device like
                     # the forward / backward pair's does (core/models.py:_NerfTrainFn): an overflowing density pass makes
-                    # this a skipped step (FusedAdam) and the host switches to bf16x3 at its next periodic look.
+                    # this a skipped step (FusedAdam); at its next periodic look the host re-calibrates the density pass's
+                    # per-layer scales (scaled fp16x3 inference) or switches to bf16x3.
                     word = torch.zeros(1, dtype=torch.int32, device=dev_)
-                    edges = ops.sample_fused(model.packed(), rays_o, rays_d, status=word, **kw_s)
+                    edges = ops.sample_fused(model.packed(probe_s), rays_o, rays_d, status=word, **kw_s)
                     ops.step_flag(dev_).bitwise_or_(word)
-                    model._train_status(dev_).bitwise_or_(word)
+                    model._train_status(dev_)[1:2].bitwise_or_(word)
                 else:
-                    edges = ops.sample_fused(model.packed(), rays_o, rays_d, **kw_s)
-                    bits = ops.range_flags(dev_) if model.range_check is True and f16 else 0
-                    if bits:
-                        model.fall_back("the sampler's density pass", bits)
-                        edges = ops.sample_fused(model.packed(), rays_o, rays_d, **kw_s)
+                    edges = model._guarded(dev_, "the sampler's density pass", probe_s,
+                                           lambda: ops.sample_fused(model.packed(probe_s), rays_o, rays_d, **kw_s))
                 ray_indices, t_starts, t_ends = ops.edges_to_packed(edges)
         elif FUSED_OCC_SAMPLER and rays_o.shape[0] >= max(1, FUSED_OCC_SAMPLER_MIN_RAYS) and \
                 _occ_fusable(estimator, model, None, render_step_size):
@@ -304,18 +340,17 @@ def render_rays(rays_o: Tensor, rays_d: Tensor, estimator, model: nn.Module, tra
                         u=uu, early_stop_eps=1e-4, alpha_thre=0.0, pos_mask=model._mask(model.pos_mask, dev_),
                         dir_mask=model._mask(model.dir_mask, dev_))
             f16 = model.fp16_family(model.PRECISIONS[model.precision])
+            probe_o = lambda: _probe_in_box(rays_o, rays_d, None, estimator.aabb)
             with torch.no_grad():
                 if needs_grad and f16 and model.range_check:
                     word = torch.zeros(1, dtype=torch.int32, device=dev_)
-                    ray_indices, t_starts, t_ends = ops.occ_sample_fused(model.packed(), rays_o, rays_d, status=word, **kw_o)
+                    ray_indices, t_starts, t_ends = ops.occ_sample_fused(model.packed(probe_o), rays_o, rays_d, status=word, **kw_o)
                     ops.step_flag(dev_).bitwise_or_(word)
-                    model._train_status(dev_).bitwise_or_(word)
+                    model._train_status(dev_)[1:2].bitwise_or_(word)
                 else:
-                    ray_indices, t_starts, t_ends = ops.occ_sample_fused(model.packed(), rays_o, rays_d, **kw_o)
-                    bits = ops.range_flags(dev_) if model.range_check is True and f16 else 0
-                    if bits:
-                        model.fall_back("the sampler's density pass", bits)
-                        ray_indices, t_starts, t_ends = ops.occ_sample_fused(model.packed(), rays_o, rays_d, **kw_o)
+                    ray_indices, t_starts, t_ends = model._guarded(
+                        dev_, "the sampler's density pass", probe_o,
+                        lambda: ops.occ_sample_fused(model.packed(probe_o), rays_o, rays_d, **kw_o))
         else:
             ray_indices, t_starts, t_ends = estimator.sampling(
                 rays_o, rays_d, sigma_fn=sigma_fn, render_step_size=render_step_size, stratified=train,
@@ -342,18 +377,27 @@ def render_rays(rays_o: Tensor, rays_d: Tensor, estimator, model: nn.Module, tra
     return output, ray_indices, t_vals
 
 
-def _deferred_frame_flagged(model, fine, dev) -> bool:
+def _range_events(model, fine) -> int:
+    """Range events (re-calibrations and fall-backs, NeRF.range_events) the frame's networks have seen so far."""
+    return sum(m.range_events for m in {id(model): model, id(fine): fine}.values() if isinstance(m, NeRF))
+
+
+def _deferred_frame_flagged(model, fine, dev, events_before: Optional[int] = None, probe=None) -> bool:
     """Deferred range check (`NeRF.range_check = "deferred"`): the one look per frame.  True when a launch of the frame
-    left the fp16 envelope; the models have then been switched to their bf16 mode (with a RuntimeWarning)."""
+    left the fp16 envelope - the LAST one (its word is polled here) or an EARLIER chunk, which the following chunk's poll
+    has consumed already (the chunk that overflowed is in the list of results all the same): any range event
+    since `events_before` says so.  The models have been re-calibrated / switched to their bf16 mode (with a
+    RuntimeWarning); the caller renders the frame again."""
     nets = [m for m in {id(model): model, id(fine): fine}.values() if isinstance(m, NeRF)]
+    earlier = events_before is not None and _range_events(model, fine) != events_before
     if not any(m.range_check == "deferred" and m.fp16_family(m.PRECISIONS[m.precision]) for m in nets):
-        return False
+        return earlier
     bits = ops.range_poll(dev)
     if not bits:
-        return False
+        return earlier
     for m in nets:
         if m.fp16_family(m.PRECISIONS[m.precision]):
-            m.fall_back("render_frame (deferred range check at the end of the frame)", bits)
+            m.fall_back("render_frame (deferred range check at the end of the frame)", bits, probe, earlier_invalid=True)
     return True
 
 
@@ -401,6 +445,7 @@ def render_frame(hwf: Tuple[int, int, float], near: float, far: float, pose: Ten
     if fused:  # (NDC frames: rays through to_ndc, then one fused launch)
         chunksize = max(int(rays_o.shape[0]), 1)
     img, depth_map = [], []
+    events0 = _range_events(model, fine)
     for co, cd in zip(U.get_chunks(rays_o, chunksize), U.get_chunks(rays_d, chunksize)):
         out = render_rays(co, cd, estimator, model, train=train, white_bkgd=white_bkgd,
                           render_step_size=render_step_size, device=device, model_fine=model_fine,
@@ -408,8 +453,9 @@ def render_frame(hwf: Tuple[int, int, float], near: float, far: float, pose: Ten
         (rgb, _, depth, _), *_ = out
         img.append(rgb)
         depth_map.append(depth)
-    if _deferred_frame_flagged(model, fine, img[0].device):
-        # some chunk is invalid and the models have been switched to bf16x3: render the frame again
+    if _deferred_frame_flagged(model, fine, img[0].device, events0):
+        # some chunk is invalid (this look, or an earlier chunk's flag consumed by the next chunk's poll) and the models
+        # have been re-calibrated / switched to bf16x3: render the frame again
         return render_frame(hwf, near, far, pose, chunksize, estimator, model, train=train, ndc=ndc,
                             white_bkgd=white_bkgd, render_step_size=render_step_size, device=device,
                             model_fine=model_fine)

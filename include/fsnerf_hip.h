@@ -42,6 +42,13 @@ typedef void* fsn_stream_t; /* hipStream_t */
                              accumulator: fp32-grade accuracy for layer scales from 2^-14 (6.1e-5) up to 65504 (both ends
                              reported through `status`, below) - the default "parity" mode */
 #define FSN_PREC_FP16 3   /* single fp16 MFMA pass */
+#define FSN_PREC_FP16X3U 4 /* round 4, inference entry points only: split-fp16 x 3 MFMA passes with UNSCALED low parts,
+                             the three products of a unit in one accumulator, no merge in the epilogue (the arithmetic of
+                             rounds 1-2: 6 % faster than FSN_PREC_FP16X3).  float32-grade because every layer's
+                             activations are kept at 2^4 .. 2^10 by a power-of-two scale per layer that is folded into
+                             the packed weights (fsn_mlp_pack_scaled; an exact transformation of the network, the outputs
+                             are unscaled by the head weights) and calibrated from the layers' measured maxima
+                             (fsn_mlp_layer_maxima).  Both ends of the calibration are reported through `status` */
 #define FSN_PREC_FP16X2 6 /* two fp16 MFMA passes: activations high+low parts, weights' high part only (the x3 blob
                              layout; inference only).  Measured accuracy in DESIGN.md - not the parity mode */
 
@@ -53,7 +60,9 @@ typedef void* fsn_stream_t; /* hipStream_t */
  * (FSN_PREC_FP16X3 / _FP16X2, forward passes): in some layer the largest |activation| over a wavefront's 16 samples x
  * all features was non-zero but below 2^-14 (an fp16 subnormal); high + scaled low part then no longer carry 22 bits
  * relative to the layer's scale - results are finite and still ~bf16x3-grade, the caller decides (the Python host
- * re-runs in FSN_PREC_BF16X3).  The bf16 modes set neither bit. */
+ * re-runs in FSN_PREC_BF16X3).  FSN_PREC_FP16X3U keeps unscaled low parts (an fp16 subnormal, fixed 2^-24 resolution,
+ * for |activation| < 2^-3): bit 1 there means that a wavefront's layer maximum was below 2^-4, i.e. the layer's scale
+ * (fsn_mlp_pack_scaled) no longer fits the data - the caller re-calibrates and re-packs.  The bf16 modes set neither bit. */
 #define FSN_STATUS_FP16_RANGE 1u
 #define FSN_STATUS_FP16_SMALL 2u
 #define FSN_STATUS_GRAD_RANGE 4u /* fsn_nerf_train_bwd with stage_scales: a stored gradient reached fp16 infinity - the
@@ -136,9 +145,29 @@ int64_t fsn_mlp_blob_bytes(const fsn_mlp_desc* desc, int prec);
  * each weight row-major [out, in] exactly as in the state_dict (src/core/models.py:96-108). */
 int fsn_mlp_pack(const fsn_mlp_desc* desc, int prec, const float* const* weights_host_of_dev,
                  const float* const* biases_host_of_dev, void* blob, fsn_stream_t stream);
+/* fsn_mlp_pack of the SCALED network (round 4; any prec, meant for FSN_PREC_FP16X3U).  layer_exps_host: n_layers + 2
+ * int32 exponents e_g, one per GEMM in kernel order (hidden layers 0 .. n_layers-1, connection, branch), or NULL = all
+ * zero = fsn_mlp_pack.  With s_g = 2^e_g the blob holds the network whose GEMM g produces s_g times the reference's
+ * activations: rows of W_g that multiply activations are scaled by s_g / s_(g-1) (the connection and the sigma head read
+ * layer n_layers-1, the branch reads the connection), rows that multiply an encoding by s_g, biases by s_g, sigma.weight
+ * by 1 / s_(n_layers-1), rgb.weight by 1 / s_branch.  Every factor is a power of two and ReLU commutes with it: in exact
+ * arithmetic the outputs are the reference's (src/core/models.py:111-143); the point is that the 16-bit parts the
+ * kernels form sit where fp16 is accurate whatever the network's own scale.  |e_g| <= 60. */
+int fsn_mlp_pack_scaled(const fsn_mlp_desc* desc, int prec, const float* const* weights_host_of_dev,
+                        const float* const* biases_host_of_dev, const int32_t* layer_exps_host, void* blob,
+                        fsn_stream_t stream);
+/* Calibration of those scales: NeRF.forward(x, dirs) on n probe samples (any blob / prec; FSN_PREC_BF16X3 on an
+ * unscaled blob has float32's range) reporting, per GEMM in kernel order, the largest |output after its activation|
+ * (ReLU layers, branch: max relu; connection: max |feat|) seen by any sample.  maxima: DEVICE float32 [n_layers + 2],
+ * zeroed by the caller (the launch takes the maximum with what is there, so several probes may accumulate).  Values are
+ * those of the blob's own scale (a blob packed with exponents e reports 2^e_g x the reference's).  No other output. */
+int fsn_mlp_layer_maxima(const fsn_mlp_desc* desc, int prec, const void* blob, const float* x, const float* dirs,
+                         const float* pos_mask, const float* dir_mask, int64_t n, float* maxima, fsn_stream_t stream);
 /* Same packing on the CPU with HOST pointers and a HOST blob (format tests, no GPU needed). */
 int fsn_mlp_pack_host(const fsn_mlp_desc* desc, int prec, const float* const* weights_host,
                       const float* const* biases_host, void* blob_host);
+int fsn_mlp_pack_scaled_host(const fsn_mlp_desc* desc, int prec, const float* const* weights_host,
+                             const float* const* biases_host, const int32_t* layer_exps_host, void* blob_host);
 /* x [n,3]; dirs [n,3] or NULL.  out [n,4]=[r,g,b,sigma] when dirs != NULL, else [n,1]=sigma.
  * pos_mask [3*(1+2*n_freqs_pos)] / dir_mask [3*(1+2*n_freqs_dir)] device pointers or NULL. */
 int fsn_mlp_fwd(const fsn_mlp_desc* desc, int prec, const void* blob, const float* x,

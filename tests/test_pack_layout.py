@@ -23,7 +23,7 @@ def bf16_to_f32(u16: np.ndarray) -> np.ndarray:
     return (u16.astype(np.uint32) << 16).view(np.float32)
 
 
-def pack_host(sd, n_layers, d_hidden, skip, nf, nfd, prec):
+def pack_host(sd, n_layers, d_hidden, skip, nf, nfd, prec, exps=None):
     fp = O.pe_freqs(nf, True).tolist()
     fd = O.pe_freqs(nfd, True).tolist()
     desc = ops.make_desc(n_layers, d_hidden, skip, fp, fd)
@@ -36,7 +36,11 @@ def pack_host(sd, n_layers, d_hidden, skip, nf, nfd, prec):
     Wp = (C.c_void_p * n)(*[w.ctypes.data for w in ws])
     Bp = (C.c_void_p * n)(*[b.ctypes.data for b in bs])
     blob = np.zeros(nbytes, dtype=np.uint8)
-    L.check(L.lib().fsn_mlp_pack_host(C.byref(desc), prec, Wp, Bp, blob.ctypes.data), "fsn_mlp_pack_host")
+    if exps is None:
+        L.check(L.lib().fsn_mlp_pack_host(C.byref(desc), prec, Wp, Bp, blob.ctypes.data), "fsn_mlp_pack_host")
+    else:
+        ex = (C.c_int32 * (n_layers + 2))(*exps)
+        L.check(L.lib().fsn_mlp_pack_scaled_host(C.byref(desc), prec, Wp, Bp, ex, blob.ctypes.data), "fsn_mlp_pack_scaled_host")
     return blob
 
 
@@ -46,14 +50,15 @@ class Emu:
     def __init__(self, blob, prec):
         hw = blob[:256].view(np.uint32)
         assert hw[0] == 0x4E53460A
-        assert hw[1] == 2, "blob layout version 2: fp16 low parts scaled by 2^11 (csrc/mlp_layout.hpp, lo_scale)"
+        assert hw[1] == 3, "blob layout version 3: low parts scaled by lo_scale(prec), per-layer exponents at words 16.."
         self.prec, self.L, self.D = int(hw[2]), int(hw[3]), int(hw[4])
         self.skip_mask, self.nf, self.nfd = int(hw[5]), int(hw[6]), int(hw[7])
         self.units_total, self.nph_full, self.nph_density = int(hw[8]), int(hw[9]), int(hw[10])
         aux_off, aux_floats, stream_off = int(hw[11]), int(hw[12]), int(hw[13])
         self.aux = blob[aux_off:aux_off + 4 * aux_floats].view(np.float32)
         self.stream = blob[stream_off:]
-        self.ub = 2048 if prec in (0, 2) else 1024
+        self.ub = 2048 if prec in (0, 2, 4) else 1024
+        self.exps = [int(np.int32(v)) for v in hw[16:16 + self.L + 2]]
         self.unit = 0
         self.NT = self.D // 32
 
@@ -63,8 +68,9 @@ class Emu:
         dec = (lambda b: b.view(np.float16).astype(np.float32)) if self.prec >= 2 else \
             (lambda b: bf16_to_f32(b.view(np.uint16)))
         hi = dec(self.stream[base:base + 1024]).reshape(64, 8).astype(np.float64)
-        if self.prec in (0, 2):
-            lo_scale = 2048.0 if self.prec == 2 else 1.0  # fp16 low parts are stored as fp16((w - hi) * 2^11)
+        if self.prec in (0, 2, 4):
+            # FSN_PREC_FP16X3: fp16 low parts are stored as fp16((w - hi) * 2^11); FSN_PREC_FP16X3U (4): unscaled
+            lo_scale = 2048.0 if self.prec == 2 else 1.0
             hi = hi + dec(self.stream[base + 1024:base + 2048]).reshape(64, 8).astype(np.float64) / lo_scale
         self.unit += 1
         return hi
@@ -164,7 +170,7 @@ def _load_sd(golden_dir, tag):
 
 
 @pytest.mark.parametrize("tag,n_layers,d_hidden", [("4x128", 4, 128), ("8x256", 8, 256)])
-@pytest.mark.parametrize("prec", [0, 1, 2, 3])
+@pytest.mark.parametrize("prec", [0, 1, 2, 3, 4])
 def test_blob_replays_to_reference_forward(golden_dir, tag, n_layers, d_hidden, prec):
     g, sd = _load_sd(golden_dir, tag)
     blob = pack_host(sd, n_layers, d_hidden, [4], 10, 4, prec)
@@ -177,11 +183,52 @@ def test_blob_replays_to_reference_forward(golden_dir, tag, n_layers, d_hidden, 
     ref = g["y_full"][:16]
     # x3 modes: weights are hi+lo (16 / 22 mantissa bits), activations exact in this model;
     # single-pass modes: 8 / 11-bit weights
-    tol = {0: 2e-5, 1: 2e-2, 2: 2e-6, 3: 3e-3}[prec]
+    tol = {0: 2e-5, 1: 2e-2, 2: 2e-6, 3: 3e-3, 4: 2e-6}[prec]
     np.testing.assert_allclose(y[:, :3], ref[:, :3], rtol=0, atol=tol)
     np.testing.assert_allclose(y[:, 3], ref[:, 3], rtol=0, atol=tol)
     ys = emu.forward(x, None, ones_p, ones_d)
     np.testing.assert_allclose(ys[:, 0], g["y_sigma"][:16, 0], rtol=0, atol=tol)
+
+
+@pytest.mark.parametrize("tag,n_layers,d_hidden", [("4x128", 4, 128), ("8x256", 8, 256)])
+@pytest.mark.parametrize("prec", [4, 0])
+def test_scaled_blob_is_the_same_network(golden_dir, tag, n_layers, d_hidden, prec):
+    """fsn_mlp_pack_scaled (round 4): per-layer powers of two folded into weight columns (activation columns by the
+    ratio of neighbouring scales, encoding columns by the layer's own), biases and the two float32 heads.  The replayed
+    blob must give the REFERENCE's outputs whatever the exponents, its hidden activations must be 2^e x the plain blob's."""
+    g, sd = _load_sd(golden_dir, tag)
+    rng = np.random.default_rng(5)
+    if prec == 0:  # bf16 has float32's exponent range: any exponents
+        exps = [int(e) for e in rng.integers(-6, 12, n_layers + 2)]
+    else:          # fp16, unscaled low parts: exponents that scale no weight DOWN (a weight of 0.05 x 2^-10 would be an
+        # fp16 subnormal; calibrated scales of a real network keep neighbouring layers within a few octaves)
+        exps = [int(e) for e in np.cumsum(rng.integers(0, 3, n_layers + 2)) + 4]
+        exps[n_layers] = exps[n_layers - 1] + 1       # connection reads layer L-1, branch the connection
+        exps[n_layers + 1] = exps[n_layers] + 2
+    blob = pack_host(sd, n_layers, d_hidden, [4], 10, 4, prec, exps)
+    emu = Emu(blob, prec)
+    assert emu.exps == exps
+    x, d = g["x"][:16], g["dirs"][:16]
+    ones_p, ones_d = np.ones(64), np.ones(32)
+    y = emu.forward(x, d, ones_p, ones_d)
+    ref = g["y_full"][:16]
+    tol = {0: 2e-5, 4: 2e-6}[prec]
+    np.testing.assert_allclose(y[:, :3], ref[:, :3], rtol=0, atol=tol)
+    np.testing.assert_allclose(y[:, 3], ref[:, 3], rtol=0, atol=tol)
+    ys = emu.forward(x, None, ones_p, ones_d)
+    np.testing.assert_allclose(ys[:, 0], g["y_sigma"][:16, 0], rtol=0, atol=tol)
+    # layer 0 of the scaled blob = 2^e0 x layer 0 of the plain one (weights on encoding columns, bias)
+    plain = Emu(pack_host(sd, n_layers, d_hidden, [4], 10, 4, prec), prec)
+    assert plain.exps == [0] * (n_layers + 2)
+    for e_, scale in ((emu, 2.0 ** exps[0]), (plain, 1.0)):
+        e_.unit = 0
+        pe = e_.encode(x, e_.nf, e_.aux[(e_.L + 5) * e_.D + 4:(e_.L + 5) * e_.D + 20], ones_p, 2)
+        _, vals = e_.layer(e_.NT, [], pe, 0, True)
+        e_.h0 = np.stack(vals) / scale
+    np.testing.assert_allclose(emu.h0, plain.h0, rtol=2e-5 if prec == 0 else 2e-6, atol=1e-6)  # (plain fp16 blob: subnormal low parts)
+    # exponents outside [-60, 60] are rejected
+    with pytest.raises(RuntimeError):
+        pack_host(sd, n_layers, d_hidden, [4], 10, 4, prec, [61] + [0] * (n_layers + 1))
 
 
 def test_blob_frequency_mask_and_wide_variants(golden_dir):

@@ -376,15 +376,26 @@ def test_c4_shape_whole_step_gradients_end_to_end():
     wloss.backward()
     assert float((tv.cpu().double() - wtv).abs().max()) < 2e-5, "the two paths resampled the same positions"
     assert abs(float(loss) - float(wloss)) < 1e-5 * max(1.0, float(wloss))
+    # Yardstick: "the reference PyTorch CPU path" END TO END in float32 - its own coarse pass and resampling, then
+    # autograd.  (Round 3 handed the float32 oracle the float64 edges, which left the resampler's amplification of a
+    # last-bit difference of the coarse pass out of the yardstick while the kernel's gradients contain it: measured
+    # tools/dbg_c4grad.py - float32 end to end is off by 3.7e-4 on layers.0.weight and 1.3e-4 .. 2.4e-4 on layers 1, 5
+    # and 6, from ONE importance sample displaced by 8.5e-7; which tensor such a sample's ReLU flips land in differs
+    # from one float32 evaluation to the next.)  Bar per tensor: 2e-4, or 3 x the float32 oracle's error on that
+    # tensor, or 1.5 x its error on its worst tensor.
     sd32 = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     kw32 = dict(kw, u=u, u_fine=uf)
-    (rgb32, _, _, _), _, _ = O.render_rays_oracle(o, d, sd32, None, cfg_of(Lx), edges_override=edges.float(), **kw32)
+    with torch.no_grad():
+        edges32 = O.render_rays_oracle(o, d, sd, None, cfg_of(Lx), **kw32)[0][3]["edges"]
+    (rgb32, _, _, _), _, _ = O.render_rays_oracle(o, d, sd32, None, cfg_of(Lx), edges_override=edges32, **kw32)
     torch.nn.functional.mse_loss(rgb32, gt).backward()
     worst = {}
+    e_f32_worst = max(_rel(sd32[name].grad, sdg[name].grad) for name, _ in m.named_parameters())
     for name, p in m.named_parameters():
         e_hip, e_f32 = _rel(p.grad, sdg[name].grad), _rel(sd32[name].grad, sdg[name].grad)
         worst[name] = (e_hip, e_f32)
-        assert e_hip < max(2e-4, 3.0 * e_f32), f"{name}: {e_hip:.2e} (float32 autograd on the oracle: {e_f32:.2e})"
+        assert e_hip < max(2e-4, 3.0 * e_f32, 1.5 * e_f32_worst), \
+            f"{name}: {e_hip:.2e} (float32 oracle end to end: {e_f32:.2e} on this tensor, {e_f32_worst:.2e} on its worst)"
     assert sum(e < 2e-4 for e, _ in worst.values()) >= len(worst) - 6, {k: f"{a:.1e}/{b:.1e}" for k, (a, b) in worst.items()}
 
 
@@ -643,6 +654,7 @@ def test_training_range_guard_is_per_call_not_a_shared_sticky_word():
     # raise the sticky word with an overflowing INFERENCE launch and leave it raised (nobody reads it)
     bad_inf = mk(sd_bad, "fp16x3").eval()
     bad_inf.range_check = False
+    bad_inf.act_scaling = False  # (round 3's inference arithmetic: the scaled network of round 4 does not overflow here)
     with torch.no_grad():
         bad_inf(x, d)
     assert int(ops.status_word(dev).item()) & 1

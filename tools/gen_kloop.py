@@ -19,7 +19,10 @@ bookkeeping per 1536-cycle pair).  The streams below
 One macro = one output pair (32 features x 16 samples of a wave) of one GEMM.
 
 Naming: FSN_KLOOP_<MODE>_<NU>_<OFF>_N<PAR>(MFMA)
-  MODE  X3 (a.w = ah.wh + [al.wh + ah.wl]) or X2 (weights' low parts dropped: ah.wh + [ah.wl] in operand terms)
+  MODE  X3 (a.w = ah.wh + [al.wh + ah.wl]), X2 (weights' low parts dropped: ah.wh + [ah.wl] in operand terms) or
+        X3S (round 4, FSN_PREC_FP16X3U: the three products of X3 into ONE accumulator tile - the low parts are stored
+        UNSCALED and the layer's activations are kept at 2^4..2^10 by per-layer power-of-two scales folded into the
+        packed weights, mlp_layout.hpp; no correction set, no merge in the epilogue: C0 / C1 are not operands)
   NU    units in the pair (2 x k-steps), OFF = units between the start of the current phase and the pair's first unit
   PAR   0: the pair accumulates in set E = v[240:247], the next pair's bias goes to O = v[248:255];
         1: the other way round.  Tile 0 (features 0-15 of the pair) is the low half of a set, tile 1 the high half.
@@ -85,7 +88,7 @@ def block(mode, nu, off, par):
         ph, o = gu // UPP, (gu % UPP) * UB
         s = u % NSETS
         emit(f"ds_read_b128 %[s{s}h], %[a{ph}] offset:{o}", True)
-        if mode == "X3":
+        if mode in ("X3", "X3S"):
             emit(f"ds_read_b128 %[s{s}l], %[a{ph}] offset:{o + 1024}", True)
         unit_last_read[u] = state["n_lds"]
 
@@ -96,7 +99,7 @@ def block(mode, nu, off, par):
             emit(fill.pop(0), True)
 
     def corr(t, s, bop, may_fill):
-        if "samechain" in ABL:   # timing experiment: the corrections into the main tile (rounds 1-2's dependency chain)
+        if mode == "X3S" or "samechain" in ABL:   # the corrections into the main tile (one accumulator per tile)
             mfma(tile(cur, t), tile(cur, t), s, bop, may_fill)
             return
         c = tile(CSET, t)
@@ -125,7 +128,7 @@ def block(mode, nu, off, par):
         # Every read of the units about to be used must have landed; LDS returns in order, so allow the reads issued
         # after their last one.  WAIT2 (default): one wait per k-step, in front of its first unit, covering both
         # of its units (one instruction less per k-step; the second unit's reads were issued a k-step ago).
-        if WAIT2 and D == 2 and mode == "X3":  # (x2: measured 1.5 % slower with the merged wait)
+        if WAIT2 and D == 2 and mode in ("X3", "X3S"):  # (x2: measured 1.5 % slower with the merged wait)
             if u % 2 == 0:
                 last = max(unit_last_read[u], unit_last_read.get(u + 1, 0))
                 ins.append(f"s_waitcnt lgkmcnt({state['n_lds'] - last})")
@@ -135,8 +138,8 @@ def block(mode, nu, off, par):
         may = u >= fill_at
         c = tile(cur, t)
         mfma(c, c, f"{s}h", f"{k}h", may)          # main sum: high x high
-        if mode == "X3":
-            corr(t, f"{s}l", f"{k}h", may)         # corrections (both scaled by 2^11 in the fp16 modes)
+        if mode in ("X3", "X3S"):
+            corr(t, f"{s}l", f"{k}h", may)         # corrections (X3: both scaled by 2^11 in the fp16 modes)
         corr(t, f"{s}h", f"{k}l", may)
     for text in fill:   # (never: every shape has room for the two bias reads)
         emit(text, True)
@@ -176,7 +179,7 @@ def main():
     out.append(f"#define FSN_KLOOP_D {D}")
     out.append(f"#define FSN_KLOOP_NSETS {NSETS}")
     out.append("")
-    for mode in ("X3", "X2"):
+    for mode in ("X3", "X2", "X3S"):
         for nu, off in SHAPES:
             for par in (0, 1):
                 out.append(emit_macro(mode, nu, off, par))
