@@ -28,6 +28,17 @@ The JSON line also carries
                  64 x 982,528 (density-only coarse pass) + 192 x 1,186,816 (full fine pass), Linear
                  layers only, 2 FLOP per MAC; `traffic` = HBM bytes per launch from the committed
                  rocprofv3 PMC pass (profiles/), or null;
+                 `clock_ghz` = the clock the chip held DURING the timed launches (s_memtime / s_memrealtime stamps of
+                 workgroup 0, fsn_render_args.clock_out), `mfma_busy_derived` = issued MFMAs x 16 cycles / (1024 SIMDs x
+                 that clock x the kernel time); `bare_stream` = the kernel's own GEMM code with nothing else in the
+                 kernel (fsn_bench_bare_stream: 256 -> 256 layers back to back, weight stream walking the real blob),
+                 launched on the same device right after the timed region, and `frac_of_bare_stream`; `fill` = the
+                 second ceiling: L2 -> LDS bytes the weight streams move per launch (every 128-sample tile streams a
+                 whole network) against the LDS-DMA fill rate MI355X_MICROARCH.md states and the bare stream reaches;
+  other_workloads - (default N=1 run only) the other rows' workloads timed in-process after the headline: `train`
+                 (configs[3]), `occgrid` (the reference's own render path), `train-occ` (its training loop body), `bf16`
+                 (the headline frame in config 5's dtype) and `bf16_c5` (configs[4]: 1600x1600, 128+256): value,
+                 ms_per_step and fraction of the MFMA peak each, so that the driver's one run records them;
   cpu_baseline - the CPU oracle (PyTorch CPU ops, same operator sequence as the reference) timed on
                  this box's host cores on a bounded sample of the same workload (rank 0, N=1 only);
   cpu_baseline_c1 - BASELINE.json configs[0] exactly (100x100 orbit pool, 4096-ray batch drawn with
@@ -84,6 +95,18 @@ def orbit_pose(phi_deg):
     return rp @ (rt @ tr)
 
 
+def cpu_model():
+    """CPU model string of the host ('core count and CPU model printed')."""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
 def cpu_baseline(target_s=15.0):
     """Oracle (kind 'port') on the host cores, bounded sample of the same workload."""
     from oracle import fsnerf_oracle as O
@@ -114,7 +137,7 @@ def cpu_baseline(target_s=15.0):
     t_probe = run(512)
     n = int(min(max(512, 512 * target_s / max(t_probe, 1e-3)), 65536))
     t = run(n)
-    return {"value": n / t, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": n / t, "unit": "rays/s", "cores": torch.get_num_threads(), "cpu_model": cpu_model(), "kind": "port",
             "sample": f"{n} rays of the 800x800 frame, 64+128 samples, two 8x256 nets, oracle/fsnerf_oracle.py "
                       f"(PyTorch CPU fp32), {t:.1f} s"}
 
@@ -163,7 +186,7 @@ def cpu_baseline_c1(dev=None, target_s=4.0):
     v_all, n_all = timed(nthr)
     v_one, n_one = timed(1)
     torch.set_num_threads(nthr)
-    out = {"value": v_all, "unit": "rays/s", "cores": nthr, "value_1_thread": v_one, "kind": "port",
+    out = {"value": v_all, "unit": "rays/s", "cores": nthr, "cpu_model": cpu_model(), "value_1_thread": v_one, "kind": "port",
            "sample": f"configs[0]: 4096-ray batch of the 90 x 100x100 orbit pool (seed 42), 64 coarse samples, 4x128 "
                      f"MLP, mask off, oracle/fsnerf_oracle.py (PyTorch CPU fp32); {n_all} batches at {nthr} threads, "
                      f"{n_one} at 1 thread"}
@@ -279,7 +302,8 @@ def train_main(args, rank, world, dev, dist, backend):
                                  "peak_tbps": 8.0}},
             "loss": float(loss),
         }
-        print(json.dumps(line), flush=True)
+        return line
+    return None
 
 
 # ---------------------------------------------------------------- occupancy-grid workload (the reference's own render path)
@@ -352,11 +376,16 @@ def occ_main(args, rank, world, dev, dist, backend):
         o, d = U.get_rays(pose, (H, W, FOCAL), dev)
         o, d = o.reshape(-1, 3), d.reshape(-1, 3)
         torch.cuda.synchronize()
-        tu = time.perf_counter()
-        with torch.no_grad():
-            (rgb_u, _, _, _), _, _ = Rm.render_rays(o, d, est, model, white_bkgd=True, render_step_size=OCC_STEP, device=dev)
-        torch.cuda.synchronize()
-        unfused_ms = (time.perf_counter() - tu) * 1e3
+        fused_sampler = Rm.FUSED_OCC_SAMPLER
+        Rm.FUSED_OCC_SAMPLER = False  # (with it on, 640,000 rays take the sampler mode of k_render_occ - the
+        try:                          # comparison would partly be the kernel against itself)
+            tu = time.perf_counter()
+            with torch.no_grad():
+                (rgb_u, _, _, _), _, _ = Rm.render_rays(o, d, est, model, white_bkgd=True, render_step_size=OCC_STEP, device=dev)
+            torch.cuda.synchronize()
+            unfused_ms = (time.perf_counter() - tu) * 1e3
+        finally:
+            Rm.FUSED_OCC_SAMPLER = fused_sampler
         same = bool(torch.equal(rgb_u, out[0].reshape(-1, 3)))
         flop_per_ray = n_cand * FLOP_DENSITY + n_kept * FLOP_FULL
         achieved = flop_per_ray * H * W / (kern_ms * 1e-3) / 1e12
@@ -378,7 +407,8 @@ def occ_main(args, rank, world, dev, dist, backend):
                          "flop_per_ray": flop_per_ray,
                          "passes_per_product": 3 if args.precision.endswith("x3") else 1},
         }
-        print(json.dumps(line), flush=True)
+        return line
+    return None
 
 
 def train_occ_main(args, rank, world, dev, dist, backend):
@@ -478,7 +508,8 @@ def train_occ_main(args, rank, world, dev, dist, backend):
                          "frac": achieved / PEAK_TFLOPS, "traffic": None, "kernel": "whole step", "flop_per_ray": flop_per_ray},
             "loss": float(loss),
         }
-        print(json.dumps(line), flush=True)
+        return line
+    return None
 
 
 # ---------------------------------------------------------------- N>1 self-launcher
@@ -571,7 +602,6 @@ def csrc_sha():
     return h.hexdigest()[:16]
 
 
-BARE_STREAM = os.path.join(ROOT, "profiles", "bare_stream.json")  # tools/ubench: what a bare GEMM-pair stream reaches
 
 
 def measured_traffic(precision):
@@ -599,6 +629,91 @@ def measured_traffic(precision):
                   "stale_value": best[1].get("hbm_bytes_per_launch")}
 
 
+def bare_stream_measure(ops, pm, dev, layers=4000):
+    """roofline.bare_stream, measured on THIS device right after the timed region (VERDICT r3 next #2b/c): the render
+    kernels' own GEMM code - hand-scheduled blocks, pair epilogues, weight-stream ring walking the hidden phases of the
+    packed fine network - as 256 -> 256 layers back to back (fsn_bench_bare_stream), ~50 ms."""
+    ops.bench_bare_stream(pm, 200)  # warm-up (clocks, instruction cache)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    n_wg, clk = ops.bench_bare_stream(pm, layers)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    c = clk.double().sum(0).tolist()
+    mfma = n_wg * 8 * layers * 384.0
+    return {"what": "the render kernels' own MFMA stream, bare: 256 -> 256 hidden layers back to back through gemm_layer "
+                    "(generated GEMM-pair blocks, pair epilogues, LDS-DMA weight ring walking the hidden phases of the "
+                    "packed fine network) on fixed activations; no encodings, heads, samplers, compositing, tile tails",
+            "mfma_tflops": mfma * 16384.0 / (ms * 1e-3) / 1e12, "algorithmic_tflops": mfma * 16384.0 / 3.0 / (ms * 1e-3) / 1e12,
+            "clock_ghz": c[0] / c[1] * 0.1 if c[1] > 0 else None, "ms": ms, "layers_per_workgroup": layers, "workgroups": n_wg,
+            "mfma_busy_derived": (8 * layers * 384.0 * 16.0 / 4.0) / (c[0] / (n_wg * 8)) if c[0] > 0 else None,
+            "fill_tbps": n_wg * layers * 262144.0 / (ms * 1e-3) / 1e12,
+            "measured": "in this run, on this device, after the timed region"}
+
+
+def other_workloads(args, dev, dist, backend):
+    """The other rows' workloads in-process (N=1 default run), so that the driver's ONE run records them (VERDICT r3
+    missing #3): a few steps each, ~10 s together.  Each entry: value, unit, ms_per_step, frac (of the 2.5 PFLOP/s MFMA
+    peak, algorithmic FLOPs of that workload), steps."""
+    import types
+    from fs_nerf_amd import ops
+    from fs_nerf_amd.render import rendering as Rm
+    out = {}
+
+    def run(name, fn, steps, warmup, precision):
+        a = types.SimpleNamespace(steps=steps, warmup=warmup, precision=precision)
+        try:
+            line = fn(a, 0, 1, dev, dist, backend)
+            out[name] = {"value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"],
+                         "frac": line["roofline"]["frac"], "steps": steps, "dtype": precision, "metric": line["metric"]}
+            for k in ("marched_samples_per_ray", "kept_samples_per_ray", "unfused_sequence_ms", "fused_equals_unfused_bitwise"):
+                if k in line["config"]:
+                    out[name][k] = line["config"][k]
+        except Exception as e:  # a failing side line must not take the headline down; it is recorded as such
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.synchronize()
+
+    run("train", train_main, 20, 3, args.precision)
+    run("occgrid", occ_main, 1, 1, args.precision)
+    run("train-occ", train_occ_main, 25, 5, args.precision)  # (the kept-sample count settles after a few optimizer steps)
+
+    def frame(name, hw, s_, ni_, steps):
+        try:
+            coarse, fine = init_sd(42), init_sd(43)
+            for m in (coarse, fine):
+                m.precision = "bf16"
+                m.to(dev).eval()
+            est = Rm.StratifiedEstimator(NEAR, FAR, s_, ni_)
+            focal = 0.5 * hw / math.tan(0.5 * 0.6911112)
+            ops.launch_timer = ev = []
+            with torch.no_grad():
+                Rm.render_frame((hw, hw, focal), NEAR, FAR, orbit_pose(0.0), 1 << 30, est, coarse, white_bkgd=True, device=dev, model_fine=fine)
+                torch.cuda.synchronize()
+                del ev[:]
+                t0 = time.perf_counter()
+                for i in range(steps):
+                    rgb, _ = Rm.render_frame((hw, hw, focal), NEAR, FAR, orbit_pose(4.0 * (i + 1)), 1 << 30, est, coarse,
+                                             white_bkgd=True, device=dev, model_fine=fine)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+            ops.launch_timer = None
+            assert bool(torch.isfinite(rgb).all())
+            flop = s_ * FLOP_DENSITY + (s_ + ni_) * FLOP_FULL
+            out[name] = {"value": steps * hw * hw / dt, "unit": "rays/s", "ms_per_step": dt / steps * 1e3,
+                         "frac": flop * hw * hw / (kern_ms * 1e-3) / 1e12 / PEAK_TFLOPS, "steps": steps, "dtype": "bf16",
+                         "metric": f"rendered rays/sec ({s_}+{ni_} samples/ray, 8x256 MLP), {hw}x{hw} frame, bf16 single pass"}
+        except Exception as e:
+            ops.launch_timer = None
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+
+    frame("bf16", 800, S, NI, 2)          # the headline frame in config 5's dtype
+    frame("bf16_c5", 1600, 128, 256, 1)   # BASELINE configs[4]: 1600x1600, 128+256, bf16 weights / activations
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -607,6 +722,7 @@ def main():
     ap.add_argument("--workload", choices=("render", "train", "occgrid", "train-occ"), default="render")
     ap.add_argument("--precision", default=os.environ.get("FSN_BENCH_PREC", "fp16x3"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the in-process train / occgrid / train-occ / bf16 lines")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="N>1: every rank its own frames (weak), or row blocks of the same frame (strong)")
     ap.add_argument("--extras", action="store_true", help="also write the per-sample outputs (weights, ...) in the timed launch")
@@ -644,7 +760,9 @@ def main():
             dist.init_process_group(backend)
 
     if args.workload in ("train", "occgrid", "train-occ"):
-        {"train": train_main, "occgrid": occ_main, "train-occ": train_occ_main}[args.workload](args, rank, world, dev, dist, backend)
+        line = {"train": train_main, "occgrid": occ_main, "train-occ": train_occ_main}[args.workload](args, rank, world, dev, dist, backend)
+        if line is not None:
+            print(json.dumps(line), flush=True)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -656,7 +774,10 @@ def main():
         m.precision = args.precision
         m.to(dev).eval()
     est = Rm.StratifiedEstimator(NEAR, FAR, S, NI)
-    pc, pf = coarse.packed(), fine.packed()
+    # (the per-layer activation scales of the fp16x3 inference path are calibrated on samples of a frame's own rays,
+    # as render_frame does on its first call)
+    probe = lambda: Rm._probe_on_rays(None, None, (orbit_pose(0.0), H, W, FOCAL, 0, H, dev), NEAR, FAR)
+    pc, pf = coarse.packed(probe), fine.packed(probe)
     torch.cuda.synchronize()
 
     from fs_nerf_amd import shard
@@ -664,6 +785,7 @@ def main():
     row0, nrows = shard.shard_rows(H, rank, world) if strong else (0, H)
     ev = []
     ops.launch_timer = ev_raw = []  # ops.render_fused brackets its launch with HIP events on the launch stream
+    clock_buf = torch.zeros(2, dtype=torch.int64, device=dev)  # (s_memtime, s_memrealtime) sums of the timed launches
 
     def step(i, timed):
         # weak scaling: ranks render different frames of the 90-frame orbit (blender.py:260-277); strong: the same one
@@ -696,14 +818,18 @@ def main():
     for i in range(args.warmup):
         step(i, False)
     barrier()
+    events0 = coarse.range_events + fine.range_events
+    ops.clock_buffer = clock_buf
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(args.warmup + i, True)
     barrier()
     dt = time.perf_counter() - t0
+    ops.clock_buffer = None
     assert bool(torch.isfinite(out[0]).all())
     assert ops.range_ok(dev), "an fp16-mode launch reported activations outside the fp16 range"
     assert coarse.precision == args.precision and fine.precision == args.precision, "no range fallback in the timed region"
+    assert coarse.range_events + fine.range_events == events0, "no re-calibration in the timed region"
     if world > 1:
         t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -717,12 +843,23 @@ def main():
         value = rays / dt
         achieved = FLOP_PER_RAY * nrows * W / (kern_ms * 1e-3) / 1e12
         traffic, traffic_src = measured_traffic(args.precision)
-        bare = None
-        if os.path.exists(BARE_STREAM):
-            try:
-                bare = json.load(open(BARE_STREAM))
-            except Exception:
-                bare = None
+        passes = 3 if args.precision.endswith("x3") else (2 if args.precision.endswith("x2") else 1)
+        clk = [int(v) for v in clock_buf.tolist()]
+        clock_ghz = clk[0] / clk[1] * 0.1 if clk[1] > 0 else None
+        mfma_per_launch = passes * FLOP_PER_RAY * nrows * W / 16384.0  # v_mfma_f32_16x16x32: 16,384 FLOP, 16 pipe cycles
+        busy = mfma_per_launch * 16.0 / (1024 * clock_ghz * 1e9 * kern_ms * 1e-3) if clock_ghz else None
+        bare = bare_stream_measure(ops, pf, dev) if args.precision in ("fp16x3", "bf16x3") else None
+        kern_mfma_tflops = passes * achieved
+        # the second ceiling: every 128-sample tile streams a whole network L2 -> LDS
+        ub = 2 if passes > 1 else 1
+        tiles_c, tiles_f = nrows * W * S // 128, nrows * W * (S + NI) // 128
+        fill_bytes = 16384.0 * ub * (tiles_c * 60 + tiles_f * 72.5)  # 960 hidden / 1160 total units of 1 KiB per part
+        if passes == 1:
+            fill_bytes /= 2  # (single-pass modes: 256-sample tiles)
+        fill = {"bytes_per_launch": fill_bytes, "tbps": fill_bytes / (kern_ms * 1e-3) / 1e12,
+                "guide_ceiling_tbps": [6.4, 6.8],
+                "bare_stream_tbps": None if bare is None else bare["fill_tbps"],
+                "note": "L2 -> LDS bytes of the weight streams (LDS-DMA), not HBM traffic: the streams hit in L2"}
         line = {
             "metric": "rendered rays/sec (64+128 samples/ray, 8x256 MLP)", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -746,10 +883,17 @@ def main():
                          "flop_per_ray": FLOP_PER_RAY,
                          # from the PMC summary stamped with these kernel sources (null when stale): the clock the chip
                          # held and the matrix-pipe busy fraction; x3 modes issue 3 MFMAs per algorithmic product
-                         "clock_ghz": traffic_src.get("clock_ghz"), "mfma_busy": traffic_src.get("mfma_busy"),
-                         "passes_per_product": 3 if args.precision.endswith("x3") else (2 if args.precision.endswith("x2") else 1),
-                         "bare_stream": bare},
+                         # measured IN this run: the clock the chip held during the timed launches (stamps of workgroup
+                         # 0) and the matrix-pipe occupancy that follows from it; the PMC pass's values beside them
+                         "clock_ghz": clock_ghz, "mfma_busy_derived": busy,
+                         "pmc_clock_ghz": traffic_src.get("clock_ghz"), "pmc_mfma_busy": traffic_src.get("mfma_busy"),
+                         "passes_per_product": passes, "mfma_tflops_issued": kern_mfma_tflops,
+                         "bare_stream": bare,
+                         "frac_of_bare_stream": None if bare is None else kern_mfma_tflops / bare["mfma_tflops"],
+                         "fill": fill},
         }
+        if world == 1 and not args.no_cpu_baseline and not args.no_other_workloads:
+            line["other_workloads"] = other_workloads(args, dev, dist, backend)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(10.0)
             line["cpu_baseline_c1"] = cpu_baseline_c1(dev)

@@ -37,7 +37,7 @@ class RenderArgs(C.Structure):
                 ("sigmas", C.c_void_p), ("rgbs", C.c_void_p), ("edges_out", C.c_void_p),
                 ("weights_coarse", C.c_void_p), ("status", C.c_void_p),
                 ("cam_pose", C.c_float * 12), ("cam_H", C.c_int32), ("cam_W", C.c_int32), ("cam_row0", C.c_int32),
-                ("cam_focal", C.c_double), ("two_phase", C.c_int32)]
+                ("cam_focal", C.c_double), ("two_phase", C.c_int32), ("clock_out", C.c_void_p)]
 
 
 class OccRenderArgs(C.Structure):
@@ -77,6 +77,7 @@ SIGNATURES = {
     "fsn_mlp_fwd": (_i, [_PD, _i, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "fsn_mlp_fwd_rays": (_i, [_PD, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i64, _vp, _vp, _vp]),
     "fsn_render_rays_fused": (_i, [_PD, _i, _vp, _vp, C.POINTER(RenderArgs), _vp]),
+    "fsn_bench_bare_stream": (_i, [_PD, _i, _vp, _i, _vp, _vp]),
     "fsn_render_rays_occgrid": (_i, [_PD, _i, _vp, C.POINTER(OccRenderArgs), _vp]),
     "fsn_occlusion_reg_fwd": (_i, [_vp, _vp, _vp, _i64, _i64, _f, _f, _i, _vp, _vp, _vp]),
     "fsn_to8b": (_i, [_vp, _i64, _vp, _vp]),

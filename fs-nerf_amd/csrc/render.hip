@@ -104,6 +104,16 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
 #ifdef FSN_STAMP
   const uint64_t t_begin = __builtin_amdgcn_s_memtime();
 #endif
+  // measurement aid (fsn_render_args.clock_out): the clock the chip holds while this launch runs
+  uint64_t clk_t0 = 0, clk_r0 = 0;
+  const bool clk_on = k.a.clock_out != nullptr && blockIdx.x == 0 && __builtin_amdgcn_readfirstlane(threadIdx.x) < 64;
+  if (clk_on) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
+  auto clk_end = [&]() __attribute__((always_inline)) {
+    if (clk_on && (threadIdx.x & 63) == 0) {
+      k.a.clock_out[0] += __builtin_amdgcn_s_memtime() - clk_t0;
+      k.a.clock_out[1] += __builtin_amdgcn_s_memrealtime() - clk_r0;
+    }
+  };
   __shared__ __attribute__((aligned(1024))) char smem[kRenderLdsBytes];
   float* auxC = reinterpret_cast<float*>(smem + kRingBytes);
   float* auxF = reinterpret_cast<float*>(smem + kRingBytes + kNetLdsBytes);
@@ -326,6 +336,7 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (S_.two_phase == 2) {  // sampler only (fsn_render_args.two_phase == 2): the resampled edges are the result
       st.drain();
+      clk_end();
       return;
     }
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
@@ -345,6 +356,7 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
     }
   }
   st.drain();
+  clk_end();
 #ifdef FSN_STAMP
   if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) {
     unsigned long long* o = g_stamp + (blockIdx.x * 8 + (threadIdx.x >> 6)) * 8;
@@ -352,6 +364,56 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
     o[4] = st.t_ko; o[5] = st.t_eo;
   }
 #endif
+}
+
+// ------------------------------------------------------------------ the kernel's own MFMA stream, bare (bench.py)
+// fsn_bench_bare_stream: 256 -> 256 hidden layers back to back through gemm_layer - the generated GEMM-pair blocks, the
+// pair epilogues, the weight stream with its LDS-DMA ring and barriers, walking the hidden phases of a real blob - on
+// fixed activations.  What the render kernels' structure reaches with nothing else in the kernel.
+template <int PREC>
+__global__ __launch_bounds__(kThreads) void k_bare_stream(const char* stream, uint32_t nph, int layers, uint64_t* clk) {
+  __shared__ __attribute__((aligned(1024))) char smem[kRingBytes + 256 * 4];
+  float* zeros = reinterpret_cast<float*>(smem + kRingBytes);
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) zeros[i] = 0.f;
+  __syncthreads();
+  NetDev net{};
+  net.aux = zeros;  // (biases: zero)
+  net.n_layers = 8;
+  WStream st;
+  st.init(smem, nullptr, 0, 0, stream, nph, 1);
+  ARing ring;
+  prime_ring<PREC, 8>(st, ring);
+  const int g = (threadIdx.x >> 4) & 3;
+  // activations as a ReLU layer of the scaled network leaves them: half of them zero, the rest spread over 2^0 .. 2^9,
+  // low parts ~2^-11 of the high parts (pseudo-random per lane: the clock the chip holds depends on the data)
+  Frag A[8], B[8];
+  Frag none[1];
+  uint32_t h = 0x9e3779b9u * (threadIdx.x + 1u) + 0x85ebca6bu * (blockIdx.x + 1u);
+  auto next = [&]() { h ^= h << 13; h ^= h >> 17; h ^= h << 5; return h; };
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t r = next();
+      const uint16_t hi = (r & 1u) ? (uint16_t)(0x3c00u + ((r >> 1) % 9u) * 0x0400u + ((r >> 8) & 0x3ffu)) : (uint16_t)0;
+      const uint16_t lo = (r & 1u) ? (uint16_t)((hi - 0x2c00u) ^ ((r >> 20) & 0x8000u)) : (uint16_t)0;
+      A[k].hi[j] = (short)hi;
+      A[k].lo[j] = (short)lo;
+    }
+  Heads heads{0.f, {0.f, 0.f, 0.f}, {0u, 0u, 0u}};
+  const uint64_t t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int l = 0; l < layers; ++l) {
+    gemm_layer<PREC, 8, 8, 0, EPI_RELU_CVT>(st, net, 0, A, none, B, heads, ring, g);
+    asm volatile("" ::"v"(B[0].hi), "v"(B[7].lo));
+  }
+  const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  st.drain();
+  if (clk && (threadIdx.x & 63) == 0) {
+    uint64_t* o = clk + 2 * (blockIdx.x * kWaves + (threadIdx.x >> 6));
+    o[0] = t1 - t0;
+    o[1] = r1 - r0;
+  }
+  if (heads.rs.fall == 0xffffffffu && clk) clk[0] = 0;  // (keeps the range tracking of the epilogues alive)
 }
 
 #undef GRP_S
@@ -478,4 +540,24 @@ extern "C" int fsn_render_rays_fused(const fsn_mlp_desc* desc, int prec, const v
     case 6: return launch_render<8, 2>(k, cus, s);
     default: return launch_render<8, 3>(k, cus, s);
   }
+}
+
+extern "C" int fsn_bench_bare_stream(const fsn_mlp_desc* desc, int prec, const void* blob, int layers, uint64_t* clock_out,
+                                     fsn_stream_t stream) {
+  FSN_REQUIRE(desc && blob && layers > 0, FSN_E_INVALID, "fsn_bench_bare_stream: bad arguments");
+  FSN_REQUIRE(desc->d_hidden == 256 && (prec == FSN_PREC_BF16X3 || prec == FSN_PREC_FP16X3 || prec == FSN_PREC_FP16X3U),
+              FSN_E_UNSUPPORTED, "fsn_bench_bare_stream: d_hidden 256 in an x3 mode only");
+  NetGeom G;
+  const char* why;
+  const int rc = build_geom(*desc, prec, G, &why);
+  FSN_REQUIRE(rc == FSN_OK, rc, "fsn_bench_bare_stream: %s", why);
+  const int cus = fsn_device_cus();
+  if (cus <= 0) return FSN_E_HIP;
+  const char* sp = static_cast<const char*>(blob) + G.stream_off;
+  hipStream_t s = as_stream(stream);
+  if (prec == FSN_PREC_BF16X3) k_bare_stream<0><<<cus, kThreads, 0, s>>>(sp, (uint32_t)G.nph_density, layers, clock_out);
+  else if (prec == FSN_PREC_FP16X3) k_bare_stream<2><<<cus, kThreads, 0, s>>>(sp, (uint32_t)G.nph_density, layers, clock_out);
+  else k_bare_stream<4><<<cus, kThreads, 0, s>>>(sp, (uint32_t)G.nph_density, layers, clock_out);
+  FSN_LAUNCH_CHECK("k_bare_stream");
+  return cus;
 }

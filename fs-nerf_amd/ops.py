@@ -353,6 +353,9 @@ def mlp_fwd(pm: PackedMLP, x: Tensor, dirs: Optional[Tensor] = None, pos_mask: O
 # profiling hook (bench.py): a list -> every render_fused launch appends a pair of HIP events recorded on the launch
 # stream right around the C-ABI call (the kernel's own duration, without the host path around it)
 launch_timer: Optional[list] = None
+# measurement hook (bench.py): a uint64 [2] device tensor -> every render_fused launch adds its (s_memtime, s_memrealtime)
+# differences to it (fsn_render_args.clock_out): the clock the chip held during the launches
+clock_buffer: Optional[Tensor] = None
 
 def mlp_fwd_rays(pm: PackedMLP, rays_o: Tensor, rays_d: Tensor, ray_indices: Tensor, t_starts: Tensor, t_ends: Tensor,
                  full: bool, pos_mask: Optional[Tensor] = None, dir_mask: Optional[Tensor] = None) -> Tensor:
@@ -459,6 +462,8 @@ def render_fused(pm_coarse: Optional[PackedMLP], pm_fine: PackedMLP, rays_o: Opt
     if pm_coarse is not None and pm_coarse.prec != pm_fine.prec:
         raise ValueError("render_fused: the coarse and the fine network must be packed in the same precision mode")
     a.status = status_word(dev).data_ptr()
+    if clock_buffer is not None:
+        a.clock_out = clock_buffer.data_ptr()
     with torch.cuda.device(dev):
         if launch_timer is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -470,6 +475,20 @@ def render_fused(pm_coarse: Optional[PackedMLP], pm_fine: PackedMLP, rays_o: Opt
             e1.record()
             launch_timer.append((e0, e1))
     return colors, opacity, depth, ex
+
+
+def bench_bare_stream(pm: PackedMLP, layers: int) -> Tuple[int, Tensor]:
+    """Measurement aid (fsn_bench_bare_stream): `layers` 256 -> 256 hidden layers back to back per workgroup through the
+    render kernels' own GEMM code, the weight stream walking the hidden phases of `pm`'s blob.  -> (workgroups launched,
+    uint64 [workgroups * 8, 2] per-wave (s_memtime, s_memrealtime) differences around the loop)."""
+    dev = pm.blob.device
+    with torch.cuda.device(dev):
+        n = L.lib().fsn_device_cus()
+        clk = torch.zeros(max(n, 1) * 8, 2, dtype=torch.int64, device=dev)
+        rc = L.lib().fsn_bench_bare_stream(C.byref(pm.desc), pm.prec, _p(pm.blob), int(layers), _p(clk), _stream())
+        if rc <= 0:
+            L.check(rc if rc < 0 else -3, "fsn_bench_bare_stream")
+    return rc, clk
 
 
 def sample_fused(pm_coarse: PackedMLP, rays_o: Tensor, rays_d: Tensor, *, near: float, far: float, n_samples: int,

@@ -231,10 +231,27 @@ typedef struct fsn_render_args {
    * NULL.  This is estimator.sampling of the hierarchical sampler (stratified edges -> density pass -> weights ->
    * inverse-CDF resampling -> sorted union) as ONE launch in front of the training forward. */
   int32_t two_phase;
+  /* Measurement aid (bench.py, NULL = off): DEVICE uint64_t[2].  Wave 0 of workgroup 0 reads the shader clock counter
+   * (s_memtime) and the constant 100 MHz counter (s_memrealtime) when it enters and when it leaves the kernel and ADDS
+   * the two differences to clock_out[0] / clock_out[1]: their ratio x 0.1 is the clock in GHz the chip held during the
+   * launch(es) - workgroup 0 lives as long as the persistent launch does. */
+  uint64_t* clock_out;
 } fsn_render_args;
 
 int fsn_render_rays_fused(const fsn_mlp_desc* desc, int prec, const void* blob_coarse,
                           const void* blob_fine, const fsn_render_args* args_host,
+                          fsn_stream_t stream);
+
+/* Measurement aid (bench.py's `roofline.bare_stream`; not part of the path): the fused kernel's own MFMA stream with
+ * nothing else in the kernel.  One persistent 512-thread workgroup per compute unit runs `layers` 256 -> 256 hidden
+ * layers back to back through the SAME code as the render kernels (mlp_dev.hpp gemm_layer: the hand-scheduled GEMM-pair
+ * blocks, the pair epilogues with ReLU / 16-bit split / range tracking, the weight stream's LDS-DMA ring with its
+ * barriers) on fixed pseudo-random activations, the weight stream WALKING the hidden phases of a real packed blob
+ * (d_hidden 256, x3 / x2 modes) like a density pass does - no encodings, heads, samplers, compositing or tile tails.
+ * clock_out: DEVICE uint64_t[2 * 8 * n_workgroups] or NULL: per wave the s_memtime and s_memrealtime differences
+ * around the loop.  Returns the number of workgroups launched (> 0) or an FSN_E_* code; per workgroup and layer the
+ * stream issues 8 waves x 384 MFMAs (v_mfma_f32_16x16x32, 16,384 FLOP each) and fills 256 KiB from L2. */
+int fsn_bench_bare_stream(const fsn_mlp_desc* desc, int prec, const void* blob, int layers, uint64_t* clock_out,
                           fsn_stream_t stream);
 
 /* ---- a6 with the occupancy estimator in the `estimator` slot: the path the reference itself renders with
