@@ -232,9 +232,19 @@ struct WStream {
     c_slot = slot_add(c_slot, 1);
     return;
 #endif
+#ifdef FSN_NLW_SKIP_VMWAIT
+    // Only the loader waves have LDS-DMA loads in flight; a non-loader wave's vmcnt counts nothing but its OWN stores
+    // (the training savers), which nobody needs to wait for here: it goes straight to the barrier, behind which every
+    // loader has seen its share of the phase land.
+    if (kLead > 0) {
+      if (is_loader) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kOpenVmcnt) : "memory");
+      asm volatile("s_barrier" ::: "memory");
+    } else
+#else
     if (kLead > 0)
       asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kOpenVmcnt) : "memory");
     else
+#endif
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((kLook - 1) * kGldsPerWave) : "memory");
     stage();
     n_base = ring + c_slot * kPhaseBytes + (FSN_TIDX & 63) * 16;
@@ -521,6 +531,9 @@ __device__ __forceinline__ void encode(float x0, float x1, float x2, int n_freqs
   if (g == 3) v[SLOTS - 2] = x2 * mask[2];
 #pragma unroll
   for (int k = 0; k < NKS; ++k) split_store<F16, X3, LS>(&v[8 * k], out[k]);
+#ifdef FSN_ABL_SAVE_NOLOADER
+  if (SAVE && (((FSN_TIDX >> 6) ^ FSN_LOADER_XOR) < (uint32_t)kLoaders)) return;
+#endif
   if constexpr (SAVE) {
     // packed T-layout (train_fused.hip): slots (k, 2i), (k, 2i+1) are rows 32k + 8g + 2i, +1 = pair-row 16k + 4g + i;
     // `save` = this lane's sample at pair-row 4g (t_layout_off); x3: the two parts of a pair as one 8-byte store

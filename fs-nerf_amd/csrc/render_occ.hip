@@ -4,8 +4,12 @@
 //   occupancy-grid march -> density pass (sigma_fn) -> visibility cull -> full pass (rgb_sigma_fn) -> packed volume
 //   integration,
 // per BATCH of rays inside a persistent workgroup.  A batch is as many whole rays as fit the LDS sample list
-// (kCap samples, kMaxRays rays), pulled in chunks of 8 (one wave marches one ray) from a global work counter, so that
-// dense and empty rays balance across the chip; a ray that no longer fits is carried into the next batch.  The sample
+// (kCap samples, kMaxRays rays), pulled in chunks of up to 8 (one wave marches one ray) from a global work counter, so
+// that dense and empty rays balance across the chip; a ray that no longer fits is carried into the next batch.  The
+// chunk size is GUIDED (round 4): a pull takes remaining / (2 x workgroups) rays, at most 8 and at least 1, so a
+// training-sized launch (4096 rays = 16 per workgroup, one dense ray = up to 8 MLP tiles) ends with single-ray pulls
+// instead of 8-ray commitments - the tail of the launch is one ray's work, not one chunk's (~3.5 ms of a 3.5-ms launch
+// before).  Rays are independent and integrated by one wave each: the results do not depend on the chunking.  The sample
 // list, densities, keep flags, colours live in LDS; the two MLP passes run on the matrix cores over 128-sample tiles
 // of the list (mlp_dev.hpp) with the weight stream running on from tile to tile and batch to batch - both kinds of
 // tile stream the same blob from its first phase, a tile announces its length when it starts (WStream::begin_tile).
@@ -40,7 +44,7 @@ struct OccLds {
   int32_t use_vis;
   // batch state (written by thread 0 between barriers)
   int64_t chunk_base, carry_base;
-  int32_t chunk_from, carry_from, stop, n_cand, n_kept, n_rays;
+  int32_t chunk_from, carry_from, chunk_take, carry_take, stop, n_cand, n_kept, n_rays;
   int32_t cnt[kWaves];
   // rays of the batch
   float rays[kMaxRays * 6];
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(kThreads) void k_render_occ(OccKArgs k) {
   int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;  // (laundered per batch below: render.hip)
   if (tid == 0) {
     S.a = k.a; S.G = k.G; S.cam_hw = k.cam_hw; S.cam_hh = k.cam_hh; S.cam_f = k.cam_f; S.use_vis = k.use_vis;
-    S.carry_from = kWaves; S.carry_base = 0;
+    S.carry_from = kWaves; S.carry_base = 0; S.carry_take = 0;
   }
   __syncthreads();
   const fsn_occ_render_args& a = S.a;
@@ -136,10 +140,16 @@ __global__ __launch_bounds__(kThreads) void k_render_occ(OccKArgs k) {
     for (;;) {
       if (tid == 0) {
         if (S.carry_from < kWaves) {
-          S.chunk_base = S.carry_base; S.chunk_from = S.carry_from; S.carry_from = kWaves;
+          S.chunk_base = S.carry_base; S.chunk_from = S.carry_from; S.chunk_take = S.carry_take; S.carry_from = kWaves;
         } else {
-          S.chunk_base = (int64_t)atomicAdd(reinterpret_cast<unsigned long long*>(a.work_counter), (unsigned long long)kWaves);
+          // guided chunk size from a (possibly stale) look at the queue: remaining / (2 x workgroups), 1 .. 8 rays
+          unsigned long long* wc = reinterpret_cast<unsigned long long*>(a.work_counter);
+          const long long seen = (long long)__hip_atomic_load(wc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          long long take = (a.R - seen) / (2ll * (long long)gridDim.x);
+          take = take < 1 ? 1 : (take > kWaves ? kWaves : take);
+          S.chunk_base = (int64_t)atomicAdd(wc, (unsigned long long)take);
           S.chunk_from = 0;
+          S.chunk_take = (int32_t)take;
         }
       }
       __syncthreads();
@@ -147,10 +157,10 @@ __global__ __launch_bounds__(kThreads) void k_render_occ(OccKArgs k) {
       // kept scalar, they are not spilled per lane - 8-byte spill stores per lane and batch were 2 GB of scratch
       // writes per frame)
       const int64_t base = uniform_i64(S.chunk_base);
-      const int from = __builtin_amdgcn_readfirstlane(S.chunk_from);
+      const int from = __builtin_amdgcn_readfirstlane(S.chunk_from), take = __builtin_amdgcn_readfirstlane(S.chunk_take);
       if (base >= a.R) break;  // (workgroup-uniform: read from LDS)
       const int64_t ray = base + wave;
-      const bool active = wave >= from && ray < a.R;
+      const bool active = wave >= from && wave < take && ray < a.R;
       float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 1.f};
       RayLattice L;
       L.any = false; L.near_r = L.t_lo = L.t_hi = 0.f; L.k0 = 0;
@@ -180,7 +190,8 @@ __global__ __launch_bounds__(kThreads) void k_render_occ(OccKArgs k) {
       __syncthreads();
       if (tid == 0) {
         S.n_cand = nc; S.n_rays = nr;
-        if (stop) { S.carry_base = base; S.carry_from = first_rej; S.stop = 1; }
+        if (stop) { S.carry_base = base; S.carry_from = first_rej; S.carry_take = take; S.stop = 1; }
+        else if (take < kWaves) S.stop = 1;  // the queue is running out: this (small) chunk is the whole batch
       }
       if (my_off >= 0) {
         if (lane == 0) {

@@ -135,6 +135,9 @@ template <bool X3>
 __device__ __forceinline__ void store_pair_parts(uint32_t* p, int tp, const Frag& o) {
   typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
   const u32x4 h = __builtin_bit_cast(u32x4, o.hi), l = __builtin_bit_cast(u32x4, o.lo);
+#ifdef FSN_ABL_SAVE_NOLOADER  // timing experiment: the loader waves of the weight stream store nothing
+  if (((threadIdx.x >> 6) ^ FSN_LOADER_XOR) < (uint32_t)kLoaders) return;
+#endif
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int pr = 16 * tp + 8 * (i >> 1) + (i & 1);
@@ -164,6 +167,9 @@ struct FwdSaver {
 #endif
     __device__ __forceinline__ void pre(int) {}
     __device__ __forceinline__ void post(int tp, float (&v)[8]) {
+#ifdef FSN_ABL_SAVE_NOLOADER
+      if (((threadIdx.x >> 6) ^ FSN_LOADER_XOR) < (uint32_t)kLoaders) return;
+#endif
       if (mk) {
         uint32_t b = 0;
 #pragma unroll

@@ -220,13 +220,15 @@ def _fused_launch(rays_o, rays_d, camera, estimator, model, model_fine, train, b
 
 
 # render_rays with gradients / extras: OccGridEstimator.sampling as one launch + one gather (ops.occ_sample_fused), for
-# calls with at least this many rays.  Measured on the reference's training step (4096 rays, 353 marched samples per ray):
-# SLOWER than the unfused sequence, 7.8-8.1 against 6.8-7.2 ms per step - the launch hands out rays in chunks of eight
-# from a work queue, 4096 rays are two chunks per workgroup, and a workgroup that draws two dense chunks marches and
-# evaluates 9,000 candidates while its neighbour has none; the standalone density pass balances 128-sample tiles over
-# the chip.  Frames (640,000 rays) are where the fused launch wins (655 against 719 ms).
+# calls with at least this many rays.  Round 3 measured it SLOWER than the unfused sequence on the reference's training
+# step (4096 rays, 353 marched samples per ray: 7.8-8.1 against 6.8-7.2 ms per step): the launch handed out rays in
+# chunks of eight, 4096 rays are two chunks per workgroup, and a workgroup that drew two dense chunks evaluated 9,000
+# candidates while its neighbour had none.  Round 4: the chunk size is guided by what is left in the queue (8 rays down
+# to 1, csrc/render_occ.hip) and the tail of the launch is one ray's work: 6.2-6.4 ms per step either way on one device
+# (bench.py --workload train-occ with FSN_FUSED_OCC_SAMPLER_MIN_RAYS=0 / 32768) - a tie, with one host read per step
+# instead of two, so the reference's own batch size takes the fused sampler now.
 FUSED_OCC_SAMPLER = True
-FUSED_OCC_SAMPLER_MIN_RAYS = 32768
+FUSED_OCC_SAMPLER_MIN_RAYS = int(__import__("os").environ.get("FSN_FUSED_OCC_SAMPLER_MIN_RAYS", "4096"))
 
 
 def _occ_fusable(estimator, model, model_fine, render_step_size: float) -> bool:

@@ -187,7 +187,7 @@ def test_fused_occupancy_sampler_is_the_unfused_sampling(dev, net, res, levels, 
     m.train()
     outs = []
     floor = Rm.FUSED_OCC_SAMPLER_MIN_RAYS
-    Rm.FUSED_OCC_SAMPLER_MIN_RAYS = 0  # (by default only calls with >= 32768 rays take the fused sampler)
+    Rm.FUSED_OCC_SAMPLER_MIN_RAYS = 0  # (by default only calls with >= 4096 rays take the fused sampler)
     for flag in (True, False):
         Rm.FUSED_OCC_SAMPLER = flag
         est.generator = torch.Generator(device=dev).manual_seed(9)
