@@ -62,6 +62,7 @@ SIGNATURES = {
     "fsn_device_cus": (_i, []),
     "fsn_get_rays": (_i, [_vp, _i, _i, _d, _i, _i, _vp, _vp, _vp]),
     "fsn_to_ndc": (_i, [_vp, _vp, _i64, _i, _i, _d, _d, _vp, _vp, _vp]),
+    "fsn_build_rays": (_i, [_vp, _i64, _i, _i, _d, _i, _d, _vp, _vp, _vp, _vp, _vp]),
     "fsn_posenc_fwd": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
     "fsn_stratified_edges": (_i, [_f, _f, _i, _i64, _vp, _i, _vp, _vp]),
     "fsn_edges_to_packed": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp]),
@@ -93,7 +94,10 @@ SIGNATURES = {
     "fsn_occgrid_march": (_i, [_vp, _vp, _i64, _vp, _i, _i, _vp, _f, _f, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fsn_packed_visibility": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _f, _f, _vp, _vp]),
     "fsn_occgrid_update": (_i, [_vp, _i64, _vp, _vp, _i64, _f, _vp, _vp, _vp]),
+    "fsn_occgrid_select": (_i, [_vp, _i, _i, _i, _vp, _i, _i64, _i64, C.c_uint64, _vp, _vp, _vp, _vp]),
+    "fsn_occgrid_update_multi": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _f, _vp]),
     "fsn_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _d, _d, _d, _d, _d, _d, _vp, _vp, _vp]),
+    "fsn_adam_step_dev": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _d, _d, _d, _d, _d, _d, _vp, _vp, _vp]),
     "fsn_weight_norm_workspace_floats": (_i64, [_i, _vp]),
     "fsn_weight_norm_fwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "fsn_weight_norm_bwd": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),

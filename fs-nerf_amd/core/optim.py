@@ -11,10 +11,11 @@ Differences from `torch.optim.Adam`, all deliberate:
     arenas are one flat buffer and one launch;
   * `zero_grad(set_to_none=True)` fills the gradient arena with zeros and keeps `p.grad` bound to it;
   * a step in which an fp16-mode training launch overflowed is skipped on the device (`ops.step_flag`, or the flag
-    slot of an all-reduced bucket): parameters and moments untouched; the host-side step counter still advances, so
-    the bias corrections run one step ahead per skipped step (overflowing ACTIVATIONS: the model leaves fp16 mode at
-    the host's next look; an overflowing GRADIENT under the backward's delayed per-stage scaling: the stage's factor
-    drops and training continues in the same mode, like a loss scaler's skipped step);
+    slot of an all-reduced bucket): parameters and moments untouched, and - round 4 - the step COUNTER too: it lives on
+    the device (`fsn_adam_step_dev`), is advanced by the launch only when the update runs, and the bias corrections are
+    formed from it there, so a skipped step is a step that did not happen, exactly as with torch's GradScaler
+    (overflowing ACTIVATIONS: the model leaves fp16 mode at the host's next look; an overflowing GRADIENT under the
+    backward's delayed per-stage scaling: the stage's factor drops and training continues in the same mode);
   * the backward kernels add into the gradient arena's views directly (`fsn_nerf_train_bwd(accumulate=1)`): autograd
     sees no gradient tensors for those parameters (parameter hooks do not fire; use `loss.backward()`);
   * `state_dict()` / `load_state_dict()` carry the flat moments and the step count (checkpoint / resume)."""
@@ -75,7 +76,17 @@ class FusedAdam(torch.optim.Optimizer):
         self.arena = FlatParams(self.param_groups[0]["params"])
         self.exp_avg = torch.zeros_like(self.arena.flat)
         self.exp_avg_sq = torch.zeros_like(self.arena.flat)
-        self.steps = 0
+        self.step_count = torch.zeros(1, dtype=torch.int32, device=self.arena.flat.device)  # updates APPLIED (device)
+        self._tick = torch.zeros(4, dtype=torch.float32, device=self.arena.flat.device)
+
+    @property
+    def steps(self) -> int:
+        """Updates applied so far (skipped steps do not count).  Reads 4 bytes back: checkpointing / tests only."""
+        return int(self.step_count.item())
+
+    @steps.setter
+    def steps(self, v: int) -> None:
+        self.step_count.fill_(int(v))
 
     @property
     def grads(self) -> FlatGrads:
@@ -97,15 +108,14 @@ class FusedAdam(torch.optim.Optimizer):
                                "re-assigned after the optimizer was built?)")
         g = self.param_groups[0]
         self.arena.grads.bind()
-        self.steps += 1
         a = self.arena
         flag = ops.step_flag(a.flat.device)
         with torch.cuda.device(a.flat.device):
-            L.check(L.lib().fsn_adam_step(ops._p(a.flat), ops._p(a.grads.flat), ops._p(self.exp_avg),
-                                          ops._p(self.exp_avg_sq), a.numel, self.steps, float(g["lr"]),
-                                          float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
-                                          float(g["weight_decay"]), float(grad_div), ops._p(flag),
-                                          ops._p(a.grads.flag_slot), ops._stream()), "fsn_adam_step")
+            L.check(L.lib().fsn_adam_step_dev(ops._p(a.flat), ops._p(a.grads.flat), ops._p(self.exp_avg),
+                                              ops._p(self.exp_avg_sq), a.numel, ops._p(self.step_count), ops._p(self._tick),
+                                              float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                              float(g["weight_decay"]), float(grad_div), ops._p(flag),
+                                              ops._p(a.grads.flag_slot), ops._stream()), "fsn_adam_step_dev")
         flag.zero_()  # the step's flag is consumed (stream order: after the launch that read it)
         a.grads.flag_slot.zero_()
         self._bump_versions()

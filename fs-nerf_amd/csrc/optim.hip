@@ -30,11 +30,32 @@ struct Segs {
 // skip_word / skip_count (device, optional): the step is a no-op - parameters and moments untouched, as when a loss
 // scaler does not call optimizer.step() - when bit 0 of *skip_word is set (this rank's training launches of the step
 // reported fp16 overflow) or *skip_count > 0 (the flag slot of the all-reduced gradient bucket: some rank did).
+// Device-side step counter (fsn_adam_step_dev): one thread decides whether the step runs, advances the counter only
+// then, and leaves the step's constants for k_adam - a skipped step does not advance the bias corrections (torch's
+// GradScaler does not call optimizer.step() either).  tick: [0] run flag (1.0 / 0.0), [1] step_size, [2] bc2_sqrt.
+__global__ void k_adam_tick(int32_t* __restrict__ step_count, float* __restrict__ tick, double lr, double beta1, double beta2,
+                            const uint32_t* __restrict__ skip_word, const float* __restrict__ skip_count) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const bool skip = (skip_word && (skip_word[0] & (FSN_STATUS_FP16_RANGE | FSN_STATUS_GRAD_RANGE))) || (skip_count && skip_count[0] > 0.f);
+  if (skip) { tick[0] = 0.f; return; }
+  const int t = step_count[0] + 1;
+  step_count[0] = t;
+  // bias corrections in double, as torch forms them in Python floats
+  const double b1t = pow(beta1, (double)t), b2t = pow(beta2, (double)t);
+  tick[0] = 1.f;
+  tick[1] = (float)(lr / (1.0 - b1t));
+  tick[2] = (float)sqrt(1.0 - b2t);
+}
+
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                        int64_t n, float step_size, float omb1, float b2, float omb2, float bc2_sqrt, float eps,
                        float wd, float grad_div, const uint32_t* __restrict__ skip_word,
-                       const float* __restrict__ skip_count) {
-  if ((skip_word && (skip_word[0] & (FSN_STATUS_FP16_RANGE | FSN_STATUS_GRAD_RANGE))) || (skip_count && skip_count[0] > 0.f)) return;
+                       const float* __restrict__ skip_count, const float* __restrict__ tick) {
+  if (tick) {  // (fsn_adam_step_dev: k_adam_tick has looked at the skip words and formed this step's constants)
+    if (tick[0] == 0.f) return;
+    step_size = tick[1];
+    bc2_sqrt = tick[2];
+  } else if ((skip_word && (skip_word[0] & (FSN_STATUS_FP16_RANGE | FSN_STATUS_GRAD_RANGE))) || (skip_count && skip_count[0] > 0.f)) return;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
   for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
     if (i + 4 <= n) {
@@ -162,7 +183,29 @@ extern "C" int fsn_adam_step(float* params, const float* grads, float* exp_avg, 
   const unsigned grid = (unsigned)(want < 8 * cus ? (want > 0 ? want : 1) : 8 * cus);
   k_adam<<<grid, 256, 0, as_stream(stream)>>>(params, grads, exp_avg, exp_avg_sq, n, (float)step_size,
                                               (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)bc2_sqrt, (float)eps, (float)weight_decay,
-                                              (float)grad_div, skip_word, skip_count);
+                                              (float)grad_div, skip_word, skip_count, nullptr);
+  FSN_LAUNCH_CHECK("k_adam");
+  return FSN_OK;
+}
+
+extern "C" int fsn_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                 int32_t* step_count, float* tick, double lr, double beta1, double beta2, double eps,
+                                 double weight_decay, double grad_div, const uint32_t* skip_word, const float* skip_count,
+                                 fsn_stream_t stream) {
+  FSN_REQUIRE(n >= 0 && beta1 >= 0 && beta1 < 1 && beta2 >= 0 && beta2 < 1 && grad_div > 0, FSN_E_INVALID,
+              "fsn_adam_step_dev: bad arguments (n=%lld)", (long long)n);
+  FSN_REQUIRE(step_count && tick, FSN_E_INVALID, "fsn_adam_step_dev: null step_count / tick");
+  if (n > 0) FSN_REQUIRE(params && grads && exp_avg && exp_avg_sq, FSN_E_INVALID, "fsn_adam_step_dev: null pointer");
+  int cus = fsn_device_cus();
+  if (cus <= 0) return FSN_E_HIP;
+  hipStream_t s = as_stream(stream);
+  k_adam_tick<<<1, 64, 0, s>>>(step_count, tick, lr, beta1, beta2, skip_word, skip_count);
+  FSN_LAUNCH_CHECK("k_adam_tick");
+  if (n == 0) return FSN_OK;
+  const int64_t want = (n / 4 + 255) / 256;
+  const unsigned grid = (unsigned)(want < 8 * cus ? (want > 0 ? want : 1) : 8 * cus);
+  k_adam<<<grid, 256, 0, s>>>(params, grads, exp_avg, exp_avg_sq, n, 0.f, (float)(1.0 - beta1), (float)beta2,
+                              (float)(1.0 - beta2), 1.f, (float)eps, (float)weight_decay, (float)grad_div, nullptr, nullptr, tick);
   FSN_LAUNCH_CHECK("k_adam");
   return FSN_OK;
 }

@@ -27,24 +27,85 @@ __global__ void k_get_rays(Pose34 P, int W, float half_w, float half_h, float fo
 }
 
 // ---------------------------------------------------------------- to_ndc
-// reference: src/utils/utilities.py:84-120
+// reference: src/utils/utilities.py:84-120.  The one definition used by k_to_ndc and k_build_rays.
+__device__ __forceinline__ void ndc_ray(float (&o)[3], float (&d)[3], float sx, float sy, float near, float two_near) {
+  const float dx = d[0], dy = d[1], dz = d[2];
+  float ox = o[0], oy = o[1], oz = o[2];
+  const float t = -(near + oz) / dz;
+  ox = ox + t * dx;
+  oy = oy + t * dy;
+  oz = oz + t * dz;
+  o[0] = sx * ox / oz;
+  o[1] = sy * oy / oz;
+  o[2] = 1.0f + two_near / oz;
+  d[0] = sx * (dx / dz - ox / oz);
+  d[1] = sy * (dy / dz - oy / oz);
+  d[2] = -two_near / oz;
+}
+
 __global__ void k_to_ndc(const float* __restrict__ ro, const float* __restrict__ rd, int64_t n,
                          float sx, float sy, float near, float two_near, float* __restrict__ no,
                          float* __restrict__ nd) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float dx = rd[3 * i], dy = rd[3 * i + 1], dz = rd[3 * i + 2];
-  float ox = ro[3 * i], oy = ro[3 * i + 1], oz = ro[3 * i + 2];
-  const float t = -(near + oz) / dz;
-  ox = ox + t * dx;
-  oy = oy + t * dy;
-  oz = oz + t * dz;
-  no[3 * i + 0] = sx * ox / oz;
-  no[3 * i + 1] = sy * oy / oz;
-  no[3 * i + 2] = 1.0f + two_near / oz;
-  nd[3 * i + 0] = sx * (dx / dz - ox / oz);
-  nd[3 * i + 1] = sy * (dy / dz - oy / oz);
-  nd[3 * i + 2] = -two_near / oz;
+  float o[3] = {ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]}, d[3] = {rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]};
+  ndc_ray(o, d, sx, sy, near, two_near);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { no[3 * i + k] = o[k]; nd[3 * i + k] = d[k]; }
+}
+
+// ---------------------------------------------------------------- dataset ray tables
+// reference: src/nerfdata/datasets/blender.py:174-191, llff.py:59-90 (torch.stack of per-pose get_rays, to_ndc over all of
+// them, min / max of {o, o + d} over all rays).  ONE launch for [n_poses, H, W]: thread = (pose, pixel); the rays go
+// straight into the [n*H*W, 3] tables; the region of interest is reduced on the way (wave min / max by shuffles, one
+// atomic per wave and component on order-preserving integer keys - min / max are exact in any order, so the result is
+// bit for bit torch's).  keys: 6 uint32, [0..2] minima, [3..5] maxima; k_aabb_init / k_aabb_finish around the launch.
+__device__ __forceinline__ uint32_t f32_key(float f) {  // monotone float -> uint32
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_f32(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+__global__ void k_aabb_init(uint32_t* __restrict__ keys) {
+  if (threadIdx.x < 3) keys[threadIdx.x] = 0xffffffffu;
+  else if (threadIdx.x < 6) keys[threadIdx.x] = 0u;
+}
+__global__ void k_aabb_finish(const uint32_t* __restrict__ keys, float div, float* __restrict__ aabb) {
+  if (threadIdx.x < 6) aabb[threadIdx.x] = key_f32(keys[threadIdx.x]) / div;
+}
+
+__global__ void k_build_rays(const float* __restrict__ poses, int64_t n_poses, int H, int W, float half_w, float half_h,
+                             float focal, int ndc, float sx, float sy, float near, float two_near,
+                             float* __restrict__ ro, float* __restrict__ rd, uint32_t* __restrict__ keys) {
+  const int64_t per = (int64_t)H * W, total = n_poses * per;
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = p < total;
+  const int64_t pc = live ? p : total - 1;
+  const int64_t pose = pc / per, pix = pc - pose * per;
+  float o[3], d[3];
+  pinhole_ray(poses + 12 * pose, half_w, half_h, focal, (int)(pix / W), (int)(pix % W), o, d);
+  if (ndc) ndc_ray(o, d, sx, sy, near, two_near);
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { rd[3 * p + k] = d[k]; ro[3 * p + k] = o[k]; }
+  }
+  if (!keys) return;
+  // (dead lanes carry a copy of the last ray: min / max unchanged)
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float e = o[k] + d[k];
+    float lo = fminf(o[k], e), hi = fmaxf(o[k], e);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      lo = fminf(lo, __shfl_xor(lo, off, 64));
+      hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(keys + k, f32_key(lo));
+      atomicMax(keys + 3 + k, f32_key(hi));
+    }
+  }
 }
 
 // ---------------------------------------------------------------- posenc
@@ -251,6 +312,30 @@ extern "C" int fsn_to_ndc(const float* rays_o, const float* rays_d, int64_t n, i
   k_to_ndc<<<nblocks(n, 256), 256, 0, as_stream(stream)>>>(rays_o, rays_d, n, sx, sy, (float)near,
                                                           (float)(2.0 * near), ndc_o, ndc_d);
   FSN_LAUNCH_CHECK("k_to_ndc");
+  return FSN_OK;
+}
+
+extern "C" int fsn_build_rays(const float* poses, int64_t n_poses, int H, int W, double focal, int ndc, double near,
+                              float* rays_o, float* rays_d, float* aabb, uint32_t* aabb_keys, fsn_stream_t stream) {
+  FSN_REQUIRE(n_poses >= 0 && H > 0 && W > 0 && focal > 0, FSN_E_INVALID,
+              "fsn_build_rays: bad geometry n=%lld H=%d W=%d focal=%g", (long long)n_poses, H, W, focal);
+  if (n_poses == 0) return FSN_OK;
+  FSN_REQUIRE(poses && rays_o && rays_d && (!aabb || aabb_keys), FSN_E_INVALID, "fsn_build_rays: null pointer");
+  const int64_t total = n_poses * (int64_t)H * W;
+  hipStream_t s = as_stream(stream);
+  if (aabb) {
+    k_aabb_init<<<1, 64, 0, s>>>(aabb_keys);
+    FSN_LAUNCH_CHECK("k_aabb_init");
+  }
+  const float sx = (float)(-1.0 / (W / (2.0 * focal))), sy = (float)(-1.0 / (H / (2.0 * focal)));
+  k_build_rays<<<nblocks(total, 256), 256, 0, s>>>(poses, n_poses, H, W, (float)(W * 0.5), (float)(H * 0.5), (float)focal,
+                                                   ndc ? 1 : 0, sx, sy, (float)near, (float)(2.0 * near), rays_o, rays_d,
+                                                   aabb ? aabb_keys : nullptr);
+  FSN_LAUNCH_CHECK("k_build_rays");
+  if (aabb) {
+    k_aabb_finish<<<1, 64, 0, s>>>(aabb_keys, 8.0f, aabb);  // aabb / 2 ** (4 - 1) (llff.py:84)
+    FSN_LAUNCH_CHECK("k_aabb_finish");
+  }
   return FSN_OK;
 }
 

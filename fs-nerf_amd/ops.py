@@ -64,6 +64,23 @@ def get_rays(pose: Tensor, H: int, W: int, focal: float, device, row0: int = 0,
     return o, d
 
 
+def build_rays(poses: Tensor, H: int, W: int, focal: float, device, ndc: bool = False, near: float = 1.0,
+               want_aabb: bool = False):
+    """Rays of all `poses` ([n, 3or4, 4]) in ONE launch (fsn_build_rays) -> (rays_o [n*H*W,3], rays_d [n*H*W,3],
+    aabb [6] or None): get_rays per pose, optional NDC mapping, and the min / max region of interest over {o, o + d}
+    (/ 2^3, llff.py:77-84) reduced inside the launch."""
+    P = torch.as_tensor(poses, dtype=torch.float32)[:, :3, :4].reshape(-1, 12).contiguous().to(device)
+    n = P.shape[0]
+    o = torch.empty(n * H * W, 3, device=P.device, dtype=torch.float32)
+    d = torch.empty_like(o)
+    aabb = torch.empty(6, device=P.device, dtype=torch.float32) if want_aabb else None
+    keys = torch.empty(6, device=P.device, dtype=torch.int32) if want_aabb else None
+    with torch.cuda.device(P.device):
+        L.check(L.lib().fsn_build_rays(_p(P), n, int(H), int(W), float(focal), 1 if ndc else 0, float(near), _p(o), _p(d),
+                                       _p(aabb), _p(keys), _stream()), "fsn_build_rays")
+    return o, d, aabb
+
+
 def to_ndc(rays_o: Tensor, rays_d: Tensor, H: int, W: int, focal: float, near: float) -> Tuple[Tensor, Tensor]:
     o, d = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d")
     n = o.numel() // 3
@@ -750,9 +767,6 @@ def occgrid_march(rays_o: Tensor, rays_d: Tensor, aabb: Sequence[float], res: in
     return ri, t0, t1, counts
 
 
-_work_counters: Dict[torch.device, Tensor] = {}
-
-
 def occ_sample_fused(pm: PackedMLP, rays_o: Tensor, rays_d: Tensor, *, aabb: Sequence[float], res: int, levels: int, bits: Tensor,
                      near_plane: float, far_plane: float, step: float, max_steps: int, u: Optional[Tensor] = None,
                      early_stop_eps: float = 1e-4, alpha_thre: float = 0.0, pos_mask: Optional[Tensor] = None,
@@ -787,9 +801,10 @@ def occ_sample_fused(pm: PackedMLP, rays_o: Tensor, rays_d: Tensor, *, aabb: Seq
     n_kept = torch.zeros(Rn, dtype=torch.int32, device=dev)
     slots = torch.empty(max(Rn, 1), int(max_steps), dtype=torch.float32, device=dev)
     a.n_kept, a.sample_t0, a.sample_cap = n_kept.data_ptr(), slots.data_ptr(), int(max_steps)
-    wc = _work_counters.get(dev)
-    if wc is None:
-        wc = _work_counters[dev] = torch.zeros(1, dtype=torch.int64, device=dev)
+    # (one queue counter PER CALL - ADVICE r3: a per-device buffer let two launches on different streams race on it; the
+    # launch zeroes it itself)
+    wc = torch.empty(1, dtype=torch.int64, device=dev)
+    keep.append(wc)
     a.work_counter = wc.data_ptr()
     a.status = (status_word(dev) if status is None else status).data_ptr()
     with torch.cuda.device(dev):
@@ -860,9 +875,10 @@ def render_occ_fused(pm: PackedMLP, rays_o: Optional[Tensor], rays_d: Optional[T
     if want_counts:
         counts = {"n_cand": torch.zeros(R, dtype=torch.int32, device=dev), "n_kept": torch.zeros(R, dtype=torch.int32, device=dev)}
         a.n_cand, a.n_kept = counts["n_cand"].data_ptr(), counts["n_kept"].data_ptr()
-    wc = _work_counters.get(dev)
-    if wc is None:
-        wc = _work_counters[dev] = torch.zeros(1, dtype=torch.int64, device=dev)
+    # (one queue counter PER CALL - ADVICE r3: a per-device buffer let two launches on different streams race on it; the
+    # launch zeroes it itself)
+    wc = torch.empty(1, dtype=torch.int64, device=dev)
+    keep.append(wc)
     a.work_counter = wc.data_ptr()
     a.status = status_word(dev).data_ptr()
     with torch.cuda.device(dev):
@@ -897,3 +913,30 @@ def occgrid_update(occs: Tensor, bits: Tensor, cells: Optional[Tensor], vals: Op
     with torch.cuda.device(occs.device):
         L.check(L.lib().fsn_occgrid_update(_p(occs), occs.numel(), _p(cells), _p(None if vals is None else _f32(vals, "vals")),
                                            n, float(decay), _p(thr), _p(bits), _stream()), "fsn_occgrid_update")
+
+
+def occgrid_select(bits: Tensor, aabb: Sequence[float], res: int, levels: int, lvl: int, all_cells: bool, n_uniform: int,
+                   n_occupied: int, seed: int, scratch: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """Cells of level `lvl` an update re-evaluates and a random point inside each (fsn_occgrid_select) ->
+    (cells int64 [n] global indices, x [n,3]); n = res^3 (all_cells) or n_uniform + n_occupied.  No host sync."""
+    res3 = res ** 3
+    n = res3 if all_cells else int(n_uniform) + int(n_occupied)
+    dev = bits.device
+    cells = torch.empty(n, dtype=torch.int64, device=dev)
+    x = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    if scratch is None and not all_cells and n_occupied > 0:
+        scratch = torch.empty(res3 // 32 + 1, dtype=torch.int32, device=dev)
+    ab = (C.c_float * 6)(*[float(v) for v in aabb])
+    with torch.cuda.device(dev):
+        L.check(L.lib().fsn_occgrid_select(_p(bits), int(res), int(levels), int(lvl), ab, 1 if all_cells else 0, int(n_uniform),
+                                           int(n_occupied), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), _p(scratch), _p(cells),
+                                           _p(x), _stream()), "fsn_occgrid_select")
+    return cells, x
+
+
+def occgrid_update_multi(occs: Tensor, pending: Tensor, cells: Tensor, vals: Tensor, decay: float) -> None:
+    """occs[c] = max(occs[c]*decay, max of the vals drawn for c); `cells` may repeat (fsn_occgrid_update_multi)."""
+    n = cells.numel()
+    with torch.cuda.device(occs.device):
+        L.check(L.lib().fsn_occgrid_update_multi(_p(occs), occs.numel(), _p(pending), _p(cells), _p(_f32(vals, "vals").reshape(-1)),
+                                                 n, float(decay), _stream()), "fsn_occgrid_update_multi")

@@ -26,6 +26,9 @@ class OccGridEstimator(nn.Module):
         self.register_buffer("occs", torch.zeros(n_cells, dtype=torch.float32))
         self.register_buffer("bits", torch.zeros(n_cells // 32, dtype=torch.int32))
         self.generator: Optional[torch.Generator] = None
+        self._updates = 0      # update_every_n_steps calls that ran (part of the draws' seed)
+        self._pending = None   # scratch of the duplicate-safe EMA / the selection's popcount prefix (device)
+        self._prefix = None
 
     # -- helpers -------------------------------------------------------------------
     @property
@@ -78,29 +81,31 @@ class OccGridEstimator(nn.Module):
     @torch.no_grad()
     def update_every_n_steps(self, step: int, occ_eval_fn: Callable, occ_thre: float = 1e-2, ema_decay: float = 0.95,
                              warmup_steps: int = 256, n: int = 16) -> None:
-        """Every n-th training step: re-evaluate cells (all of them during warm-up, else res^3/4 uniform + res^3/4
-        occupied ones) at a random point inside each, occs = max(occs*decay, occ), binaries = occs > min(mean, thre)."""
+        """Every n-th training step (run-nerf.py:288-295): re-evaluate cells - all of them during warm-up, else res^3/4
+        drawn uniformly + res^3/4 drawn uniformly from the occupied ones, with replacement - at a random point inside
+        each, occs = max(occs*decay, occ), binaries = occs > min(mean, thre).
+        Round 4: selection, jitter and the duplicate-safe EMA are kernels reading the bit field directly
+        (fsn_occgrid_select / fsn_occgrid_update_multi); no host sync, no bool expansion of the grid.  Randomness is a
+        counter-based hash of (seed, draw): seed = the estimator generator's (or torch's) initial seed and the number of
+        updates made so far - `oracle.occgrid_select` restates it."""
         if not self.training or step % n != 0:
             return
-        res, dev = self.resolution, self.occs.device
-        res3 = res ** 3
+        res, res3 = self.resolution, self.resolution ** 3
+        if self._pending is None or self._pending.device != self.occs.device:
+            self._pending = torch.zeros(self.occs.numel(), dtype=torch.int32, device=self.occs.device)
+            self._prefix = torch.empty(res3 // 32 + 1, dtype=torch.int32, device=self.occs.device)
         for lvl in range(self.levels):
-            if step < warmup_steps:
-                idx = torch.arange(res3, device=dev)
-            else:
-                k = res3 // 4
-                uni = torch.randint(res3, (k,), device=dev, generator=self.generator)
-                occd = torch.nonzero(self.binaries[lvl].reshape(-1)).reshape(-1)
-                if occd.numel() > k:
-                    occd = occd[torch.randint(occd.numel(), (k,), device=dev, generator=self.generator)]
-                idx = torch.unique(torch.cat([uni, occd]))
-            iz, iy, ix = idx % res, (idx // res) % res, idx // (res * res)
-            coords = torch.stack([ix, iy, iz], dim=-1).float()
-            x = (coords + torch.rand(idx.numel(), 3, device=dev, generator=self.generator)) / res
-            lo, hi = self.level_aabb(lvl)
-            lo_t, hi_t = torch.tensor(lo, device=dev), torch.tensor(hi, device=dev)
-            x = lo_t + x * (hi_t - lo_t)
+            seed = self.update_seed(lvl)
+            warm = step < warmup_steps
+            cells, x = ops.occgrid_select(self.bits, self.aabb, res, self.levels, lvl, warm, res3 // 4, res3 // 4, seed,
+                                          self._prefix)
             occ = occ_eval_fn(x).reshape(-1).float()
-            ops.occgrid_update(self.occs, self.bits, (lvl * res3 + idx).contiguous(), occ, ema_decay, None)
+            ops.occgrid_update_multi(self.occs, self._pending, cells, occ, ema_decay)
+        self._updates += 1
         thr = torch.clamp(self.occs.mean(), max=occ_thre).reshape(1)
         ops.occgrid_update(self.occs, self.bits, None, None, 1.0, thr)
+
+    def update_seed(self, lvl: int = 0) -> int:
+        """64-bit seed of the NEXT update's draws at level `lvl` (see update_every_n_steps)."""
+        base = self.generator.initial_seed() if self.generator is not None else torch.initial_seed()
+        return (base * 0x9E3779B97F4A7C15 + self._updates * 0x100000001B3 + lvl * 0x632BE59BD9B4E019) & 0xFFFFFFFFFFFFFFFF

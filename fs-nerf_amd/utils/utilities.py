@@ -39,23 +39,16 @@ def get_chunks(inputs: Tensor, chunksize: int) -> List[Tensor]:
 
 def build_rays(poses, hwf: Tuple[int, int, float], device: torch.device = torch.device("cuda"),
                ndc: bool = False) -> Tuple[Tensor, Tensor, Tensor]:
-    """The datasets' ray precompute (src/nerfdata/datasets/blender.py:174-191, llff.py:59-90) on the
-    device: rays of every pose written straight into one [n*H*W, 3] pair (no per-pose cat / stack), optional NDC
-    mapping over all of them, and the region of interest the reference derives for its estimator:
-    NDC -> aabb = [min, max] over {o, o + d} / 2^3 (llff.py:77-84), else [-1.5]*3 + [1.5]*3 (blender.py:140)."""
+    """The datasets' ray precompute (src/nerfdata/datasets/blender.py:174-191, llff.py:59-90) as ONE
+    launch (ops.build_rays / fsn_build_rays): rays of every pose written straight into one [n*H*W, 3] pair (no per-pose
+    cat / stack), optional NDC mapping of all of them in the same pass, and the region of interest the reference derives
+    for its estimator reduced on the way: NDC -> aabb = [min, max] over {o, o + d} / 2^3 (llff.py:77-84), else
+    [-1.5]*3 + [1.5]*3 (blender.py:140).  (Round 3: a Python loop of per-pose launches, a to_ndc launch and five torch
+    reductions.)"""
     H, W, focal = hwf
     device = _need_gpu(device, "build_rays")
-    n, per = len(poses), int(H) * int(W)
-    rays_o = torch.empty(n * per, 3, device=device, dtype=torch.float32)
-    rays_d = torch.empty_like(rays_o)
-    for i, pose in enumerate(poses):
-        ops.get_rays(pose, int(H), int(W), float(focal), device, out=(rays_o[i * per:(i + 1) * per], rays_d[i * per:(i + 1) * per]))
-    if ndc:
-        rays_o, rays_d = to_ndc(rays_o, rays_d, hwf, 1.0)
-        ends = rays_o + rays_d
-        lo = torch.minimum(rays_o.amin(dim=0), ends.amin(dim=0))
-        hi = torch.maximum(rays_o.amax(dim=0), ends.amax(dim=0))
-        aabb = torch.cat([lo, hi]) / 2 ** (4 - 1)
-    else:
+    P = torch.stack([torch.as_tensor(p, dtype=torch.float32)[:3, :4] for p in poses]) if len(poses) else torch.zeros(0, 3, 4)
+    rays_o, rays_d, aabb = ops.build_rays(P, int(H), int(W), float(focal), device, ndc=ndc, near=1.0, want_aabb=ndc)
+    if not ndc:
         aabb = torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5], device=device)
     return rays_o, rays_d, aabb

@@ -87,6 +87,16 @@ int fsn_get_rays(const float* pose_host, int H, int W, double focal, int row0, i
 int fsn_to_ndc(const float* rays_o, const float* rays_d, int64_t n, int H, int W, double focal,
                double near, float* ndc_o, float* ndc_d, fsn_stream_t stream);
 
+/* ---- f4: the datasets' ray tables       src/nerfdata/datasets/blender.py:174-191, llff.py:59-90
+ * get_rays of ALL poses (DEVICE [n_poses, 12]: rows 0..2 of each camera-to-world matrix) in one launch, straight into
+ * rays_o / rays_d [n_poses*H*W, 3] (pose-major, then row-major pixels: torch.stack(...).reshape(-1, 6) of the reference),
+ * optionally mapped to NDC (utilities.py:84-120 with `near`), and - when aabb != NULL - the region of interest the
+ * reference derives for its estimator (llff.py:77-84): aabb[0..2] = min, aabb[3..5] = max over all rays of {o, o + d},
+ * divided by 2^(4-1); reduced inside the same launch (aabb_keys: 6 uint32 of DEVICE scratch).  Bit for bit the per-pose
+ * fsn_get_rays / fsn_to_ndc / torch min-max sequence. */
+int fsn_build_rays(const float* poses, int64_t n_poses, int H, int W, double focal, int ndc, double near,
+                   float* rays_o, float* rays_d, float* aabb, uint32_t* aabb_keys, fsn_stream_t stream);
+
 /* ---- a4: PositionalEncoder.forward(x)                    src/core/models.py:43-50
  * x [n, d_in] -> out [n, d_in*(1+2*n_freqs)], block order x, sin f0, cos f0, sin f1, ...
  * freqs_host: n_freqs float32 values (models.py:31-34).  mask (device, [d_out]) may be NULL:
@@ -389,6 +399,14 @@ int fsn_composite_packed_bwd(const float* sigmas, const float* rgbs, const float
 int fsn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int step,
                   double lr, double beta1, double beta2, double eps, double weight_decay, double grad_div,
                   const uint32_t* skip_word, const float* skip_count, fsn_stream_t stream);
+/* fsn_adam_step with the step counter ON THE DEVICE (round 4): step_count (DEVICE int32[1]) holds the number of updates
+ * applied so far; a first one-thread launch looks at skip_word / skip_count, and only when the step runs advances the
+ * counter and forms the bias-correction constants (double precision, torch's expressions) into tick (DEVICE float[4],
+ * scratch); the update launch reads them.  A skipped step therefore does not advance the bias corrections - as with
+ * torch's GradScaler, which does not call optimizer.step() on an overflowing step - and the host never needs the count. */
+int fsn_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t* step_count,
+                      float* tick, double lr, double beta1, double beta2, double eps, double weight_decay, double grad_div,
+                      const uint32_t* skip_word, const float* skip_count, fsn_stream_t stream);
 int64_t fsn_weight_norm_workspace_floats(int n_seg, const int64_t* seg_len_host);
 int fsn_weight_norm_fwd(const float* arena, int n_seg, const int64_t* seg_off_host, const int64_t* seg_len_host, int l2,
                         float* workspace, float* out, fsn_stream_t stream);
@@ -418,6 +436,21 @@ int fsn_packed_visibility(const float* sigmas, const float* t_starts, const floa
                           fsn_stream_t stream);
 int fsn_occgrid_update(float* occs, int64_t n_cells, const int64_t* cells, const float* vals, int64_t n, float decay,
                        const float* threshold_dev, uint32_t* bits, fsn_stream_t stream);
+/* update_every_n_steps on the device (round 4; run-nerf.py:288-295): which cells of level `lvl` an update re-evaluates,
+ * and where.  all_cells != 0 (warm-up): draw i is cell i, n = res^3.  Else n = n_uniform + n_occupied draws WITH
+ * replacement: the first n_uniform uniform over the level's cells, the rest uniform over its OCCUPIED cells read straight
+ * from the bit field (popcount prefix over its words in prefix_scratch, DEVICE int32 [res^3/32 + 1]; uniform when the
+ * level is empty).  Each draw gets a point uniform inside its cell of the level's box.  Randomness: the counter-based
+ * hash of csrc/occgrid.hip (occ_rand) of (seed, draw index) - no generator state, no host sync, restated by the oracle.
+ * cells: int64 [n] (global cell index, + lvl res^3), x: [n,3].
+ * fsn_occgrid_update_multi: fsn_occgrid_update's EMA for draws that may repeat a cell: occs[c] = max(occs[c] * decay,
+ * max of the vals drawn for c) - the maximum is taken first (pending: DEVICE uint32 [n_cells], all zero between calls),
+ * so the result does not depend on the order of the draws. */
+int fsn_occgrid_select(const uint32_t* bits, int res, int levels, int lvl, const float* aabb_host, int all_cells,
+                       int64_t n_uniform, int64_t n_occupied, uint64_t seed, int32_t* prefix_scratch, int64_t* cells,
+                       float* x, fsn_stream_t stream);
+int fsn_occgrid_update_multi(float* occs, int64_t n_cells, uint32_t* pending, const int64_t* cells, const float* vals,
+                             int64_t n, float decay, fsn_stream_t stream);
 
 /* f3: to8b(x) = (255 * clip(x, 0, 1)).astype(uint8)                    src/render/rendering.py:21 */
 int fsn_to8b(const float* x, int64_t n, uint8_t* out, fsn_stream_t stream);

@@ -486,3 +486,51 @@ def packed_visibility(sigmas: Tensor, t_starts: Tensor, t_ends: Tensor, ray_indi
         T = torch.exp(-(torch.cumsum(s, 0) - s))
         keep[m] = (T >= early_stop_eps) & ((1.0 - torch.exp(-s)) >= alpha_thre)
     return keep
+
+
+# ---------------------------------------------------------------- occupancy-grid update: cell selection (round 4)
+# Build's own definition (nerfacc is absent: parity unpinned) of which cells OccGridEstimator.update_every_n_steps
+# (call site src/run-nerf.py:288-295) re-evaluates and where: csrc/occgrid.hip (occ_rand, k_occ_select) restated with numpy
+# integers.  Test infrastructure only.
+def _occ_mix(x):
+    import numpy as np
+    x = x.astype(np.uint64) & 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x846CA68B) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
+def occ_rand(i, k: int, seed: int):
+    """draw i (array) of stream k of the update with 64-bit `seed` -> uint32 values (as uint64 array)."""
+    import numpy as np
+    lo, hi = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    i = np.asarray(i, dtype=np.uint64)
+    return _occ_mix(_occ_mix((i + lo) & 0xFFFFFFFF) ^ np.uint64((hi + 0x9E3779B9 * (k + 1)) & 0xFFFFFFFF))
+
+
+def occgrid_select(binaries_lvl: Tensor, aabb_lvl, res: int, all_cells: bool, n_uniform: int, n_occupied: int, seed: int):
+    """-> (cells int64 [n] indices inside the level, x float32 [n,3]).  binaries_lvl: [res,res,res] bool of the level
+    (cell index (ix*res + iy)*res + iz), aabb_lvl = (lo[3], hi[3]) of the level's box."""
+    import numpy as np
+    res3 = res ** 3
+    n = res3 if all_cells else n_uniform + n_occupied
+    i = np.arange(n, dtype=np.uint64)
+    if all_cells:
+        cell = i.copy()
+    else:
+        r = occ_rand(i, 0, seed)
+        occ_idx = np.flatnonzero(binaries_lvl.reshape(-1).cpu().numpy())  # ascending = (word, bit) order of the bit field
+        cell = r % np.uint64(res3)
+        if occ_idx.size > 0 and n_occupied > 0:
+            j = (r[n_uniform:] % np.uint64(occ_idx.size)).astype(np.int64)
+            cell[n_uniform:] = occ_idx[j].astype(np.uint64)
+    cell = cell.astype(np.int64)
+    ix, iy, iz = cell // (res * res), (cell // res) % res, cell % res
+    u = [(occ_rand(i, k, seed) >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0) for k in (1, 2, 3)]
+    lo, hi = [np.float32(v) for v in aabb_lvl[0]], [np.float32(v) for v in aabb_lvl[1]]
+    fr = np.float32(res)
+    x = np.stack([lo[a] + ((c.astype(np.float32) + u[a]) / fr) * (hi[a] - lo[a]) for a, c in enumerate((ix, iy, iz))], -1)
+    return torch.from_numpy(cell), torch.from_numpy(x.astype(np.float32))

@@ -94,6 +94,20 @@ def test_build_rays_matches_the_dataset_recipe(ndc):
     assert ro.shape == (5 * 12 * 16, 3)
     assert torch.allclose(ro.cpu(), wo, rtol=1e-5, atol=1e-5) and torch.allclose(rd.cpu(), wd, rtol=1e-5, atol=1e-5)
     assert torch.allclose(aabb.cpu(), want, rtol=1e-4, atol=1e-5)
+    # ONE launch (round 4) = the per-pose sequence it replaces, bit for bit: get_rays per pose, to_ndc over all of them,
+    # torch's min / max reductions (min / max are exact in any order); also at a size that is not a multiple of the
+    # block, where the last wave's dead lanes must not disturb the reduction
+    for hwf2 in (hwf, (7, 9, 11.0)):
+        ro2, rd2, aabb2 = U.build_rays(poses, hwf2, dev, ndc=ndc)
+        so = torch.cat([U.get_rays(p, hwf2, dev)[0].reshape(-1, 3) for p in poses])
+        sd_ = torch.cat([U.get_rays(p, hwf2, dev)[1].reshape(-1, 3) for p in poses])
+        if ndc:
+            so, sd_ = U.to_ndc(so, sd_, hwf2, 1.0)
+            e2 = so + sd_
+            a_want = torch.cat([torch.minimum(so.amin(0), e2.amin(0)), torch.maximum(so.amax(0), e2.amax(0))]) / 8
+            assert torch.equal(aabb2, a_want)
+        assert torch.equal(ro2, so) and torch.equal(rd2, sd_)
+    assert U.build_rays([], hwf, dev, ndc=ndc)[0].shape == (0, 3)
 
 
 @pytest.mark.gpu

@@ -132,20 +132,40 @@ def test_update_and_render_through_reference_call_shape():
     est.update_every_n_steps(step=0, occ_eval_fn=occ_eval_fn, occ_thre=1e-2)
     occ_frac = float(est.binaries.float().mean())
     assert 0.0 < occ_frac < 1.0
-    # replay the warm-up update: every cell, one random point inside it, occs = max(0 * decay, sigma * step)
-    g2 = torch.Generator(device=dev).manual_seed(123)
-    idx = torch.arange(32 ** 3, device=dev)
-    coords = torch.stack([idx // 1024, (idx // 32) % 32, idx % 32], -1).float()
-    x_c = (coords + torch.rand(32 ** 3, 3, device=dev, generator=g2)) / 32 * 3.0 - 1.5
+    # replay the warm-up update with the oracle's restatement of the device-side selection (round 4: counter-based
+    # randomness, no generator state): every cell, one random point inside it, occs = max(0 * decay, sigma * step)
+    from fs_nerf_amd import ops
+    est2 = OccGridEstimator(roi_aabb=torch.tensor(AABB), resolution=32, levels=1).to(dev).train()
+    est2.generator = torch.Generator(device=dev).manual_seed(123)
+    seed0 = est2.update_seed(0)
+    cells_o, x_o = O.occgrid_select(est2.binaries[0], est2.level_aabb(0), 32, True, 0, 0, seed0)
+    cells_h, x_h = ops.occgrid_select(est2.bits, est2.aabb, 32, 1, 0, True, 0, 0, seed0)
+    assert torch.equal(cells_h.cpu(), cells_o) and torch.equal(x_h.cpu(), x_o), "selection + jitter = the oracle's, bit for bit"
     with torch.no_grad():
-        dens = m(x_c).reshape(-1) * step
+        dens = m(x_o.to(dev)).reshape(-1) * step
     assert torch.allclose(est.occs, dens.clamp(min=0.0), rtol=1e-5, atol=1e-6)
     thr = min(float(est.occs.mean()), 1e-2)
     assert torch.equal(est.binaries.reshape(-1), est.occs > thr)
     est.update_every_n_steps(step=1, occ_eval_fn=occ_eval_fn)  # not a multiple of n: no-op
-    before = est.occs.clone()
+    before, bin_before, bits_before = est.occs.clone(), est.binaries[0].clone(), est.bits.clone()
+    seed1 = est.update_seed(0)
     est.update_every_n_steps(step=512, occ_eval_fn=occ_eval_fn)  # past warm-up: subset + EMA decay
     assert not torch.equal(before, est.occs)
+    # ... replayed: res^3/4 uniform draws + res^3/4 draws from the occupied cells (read from the bit field on the device),
+    # duplicates resolved by a maximum, every touched cell decayed exactly once
+    k = 32 ** 3 // 4
+    cells_o, x_o = O.occgrid_select(bin_before, est.level_aabb(0), 32, False, k, k, seed1)
+    cells_h, x_h = ops.occgrid_select(bits_before, est.aabb, 32, 1, 0, False, k, k, seed1)
+    assert torch.equal(cells_h.cpu(), cells_o) and torch.equal(x_h.cpu(), x_o), "the device's draws = the oracle's"
+    assert bool(bin_before.reshape(-1)[cells_o[k:]].all()), "the second half of the draws are occupied cells"
+    with torch.no_grad():
+        v = (m(x_o.to(dev)).reshape(-1) * step).cpu()
+    want = before.cpu().clone()
+    best = torch.full_like(want, float("-inf")).scatter_reduce(0, cells_o, v, "amax", include_self=True)
+    hit = torch.isfinite(best)
+    want[hit] = torch.maximum(want[hit] * 0.95, best[hit])
+    assert torch.allclose(est.occs.cpu(), want, rtol=1e-5, atol=1e-6)
+    assert int(hit.sum()) < 2 * k, "draws with replacement: some cells were drawn more than once"
     # render + one optimisation step through the packed path
     opt = torch.optim.Adam(m.parameters(), lr=1e-3)
     (rgb, opacity, depth, extras), ri, tv = Rm.render_rays(o, d, est, m, train=True, white_bkgd=True,

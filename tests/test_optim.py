@@ -161,8 +161,23 @@ def test_fused_adam_skips_a_flagged_step_and_checkpoints_its_state():
             assert torch.equal(p.detach(), b), f"{which}: a flagged step must not move the parameters"
         assert torch.equal(opt.exp_avg, m0) and torch.equal(opt.exp_avg_sq, v0), f"{which}: nor the moments"
         assert int(ops.step_flag(dev).item()) == 0 and float(opt.grads.flag_slot.item()) == 0.0, "flag consumed"
+        assert opt.steps == 1, f"{which}: a skipped step does not advance the (device-side) step counter"
+    # ... so the bias corrections of the next clean step are those of step 2: the same update torch.optim.Adam makes when
+    # a GradScaler withheld the two flagged steps (round 3 counted them on the host)
+    ref_net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3)).to(dev)
+    ref_net.load_state_dict({k: v.clone() for k, v in zip(ref_net.state_dict(), before)})
+    ref_opt = torch.optim.Adam(ref_net.parameters(), lr=1e-2)
+    ref_opt.zero_grad()
+    ref_net(x).square().sum().backward()
+    for p, m_, v_ in zip(ref_net.parameters(), torch.split(m0, [p.numel() for p in ref_net.parameters()]),
+                         torch.split(v0, [p.numel() for p in ref_net.parameters()])):
+        ref_opt.state[p] = {"step": torch.tensor(1.0), "exp_avg": m_.view_as(p).clone(), "exp_avg_sq": v_.view_as(p).clone()}
+    ref_opt.step()
     one_step(opt, net)
+    assert opt.steps == 2
     assert not torch.equal(next(net.parameters()).detach(), before[0]), "the next clean step updates again"
+    for p, q in zip(net.parameters(), ref_net.parameters()):
+        assert float((p.detach() - q.detach()).abs().max()) <= 2e-7 * max(1.0, float(q.detach().abs().max())), "step 2's bias corrections"
     # checkpoint / resume
     sd_opt, sd_net = copy.deepcopy(opt.state_dict()), copy.deepcopy(net.state_dict())
     one_step(opt, net)
