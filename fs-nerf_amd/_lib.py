@@ -60,6 +60,8 @@ SIGNATURES = {
     "fsn_version": (_i, []),
     "fsn_last_error": (C.c_char_p, []),
     "fsn_device_cus": (_i, []),
+    "fsn_debug_report": (_i, [_vp]),
+    "fsn_debug_selftest": (_i, []),
     "fsn_get_rays": (_i, [_vp, _i, _i, _d, _i, _i, _vp, _vp, _vp]),
     "fsn_to_ndc": (_i, [_vp, _vp, _i64, _i, _i, _d, _d, _vp, _vp, _vp]),
     "fsn_build_rays": (_i, [_vp, _i64, _i, _i, _d, _i, _d, _vp, _vp, _vp, _vp, _vp]),

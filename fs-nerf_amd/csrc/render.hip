@@ -27,6 +27,9 @@
 
 namespace fsn {
 
+FSN_DEBUG_DEFINE_RECORD(g_dbg_render)
+#define FSN_DEBUG_RECORD g_dbg_render
+
 #ifdef FSN_RENDER_BIG  // experiment: groups of up to 8 rays (158.8 KB of LDS)
 constexpr int kMaxGroupSamples = 1536;  // G * (S + n_imp) <= this
 constexpr int kMaxGroupCoarse = 768;    // G * S <= this
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
       if (tid < GRP_G * 6) {
         const int g = tid / 6, c = tid - 6 * g;
         const int64_t ray = min(r0 + g, GRP_R - 1);
-        S_.rays[tid] = c < 3 ? a.rays_o[3 * ray + c] : a.rays_d[3 * ray + c - 3];
+        FSN_AT(S_.rays, tid) = c < 3 ? a.rays_o[3 * ray + c] : a.rays_d[3 * ray + c - 3];
       }
     } else if (tid < GRP_G) {
       const int64_t ray = min(r0 + tid, GRP_R - 1);
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
       float o[3], d[3];
       pinhole_ray(a.cam_pose, S_.cam_hw, S_.cam_hh, S_.cam_f, h, w, o, d);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { S_.rays[6 * tid + c] = o[c]; S_.rays[6 * tid + 3 + c] = d[c]; }
+      for (int c = 0; c < 3; ++c) { FSN_AT(S_.rays, 6 * tid + c) = o[c]; FSN_AT(S_.rays, 6 * tid + 3 + c) = d[c]; }
     }
   };
   // stratified interval edges -> density pass of the coarse net (sigma_fn, rendering.py:58-64) -> per-ray weights,
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
       const int g = small_div(e, GRP_S + 1), i = e - g * (GRP_S + 1);
       const int64_t ray = min(r0 + g, GRP_R - 1);
       const float* ur = a.u_mode == 1 ? a.u + ray : (a.u_mode == 2 ? a.u + ray * (GRP_S + 1) : nullptr);
-      S_.edgesC[e] = stratified_edge(a.near, S_.step, GRP_S, i, a.u_mode, ur);
+      FSN_AT(S_.edgesC, e) = stratified_edge(a.near, S_.step, GRP_S, i, a.u_mode, ur);
     }
     lds_barrier();
     if (!GRP_HIER) return;
@@ -213,31 +216,32 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
       auto source = [&](int idx) {
         const int idc = min(idx, GRP_G * GRP_S - 1);
         const int g = small_div(idc, GRP_S), i = idc - g * GRP_S;
-        return RaySrc{S_.rays + 6 * g, S_.edgesC + g * (GRP_S + 1) + i};
+        return RaySrc{FSN_SPAN(S_.rays, 6 * g, 6), FSN_SPAN(S_.edgesC, g * (GRP_S + 1) + i, 2)};
       };
       if constexpr (NG == 1) {
         const int idx = slot(0);
         float sigma, rgb[3];
         mlp_tile<NT, PREC, false>(st, netC, source(idx), ring, sigma, rgb);
-        if (lane < 16 && idx < GRP_G * GRP_S) S_.sigC[idx] = sigma;
+        if (lane < 16 && idx < GRP_G * GRP_S) FSN_AT(S_.sigC, idx) = sigma;
       } else {
         float sigma[2], rgb[2][3];
         mlp_tile2<NT, PREC, false>(st, netC, source(slot(0)), source(slot(1)), ring, sigma, rgb);
         const int q = (lane >> 4) & 1, idx = slot(q);  // lanes 0-15 store group 0, lanes 16-31 group 1
-        if (lane < 32 && idx < GRP_G * GRP_S) S_.sigC[idx] = sigma[q];
+        if (lane < 32 && idx < GRP_G * GRP_S) FSN_AT(S_.sigC, idx) = sigma[q];
       }
     }
     st.pass_end();
     lds_barrier();
     for (int g = wave; g < GRP_G; g += kWaves) {
       const int64_t ray = min(r0 + g, GRP_R - 1);
-      float* wc = S_.wC + g * GRP_S;
-      weights_ray(S_.sigC + g * GRP_S, S_.edgesC + g * (GRP_S + 1), GRP_S, wc);
+      float* wc = FSN_SPAN(S_.wC, g * GRP_S, GRP_S);
+      weights_ray(FSN_SPAN(S_.sigC, g * GRP_S, GRP_S), FSN_SPAN(S_.edgesC, g * (GRP_S + 1), GRP_S + 1), GRP_S, wc);
       __builtin_amdgcn_wave_barrier();
       if (a.weights_coarse && r0 + g < GRP_R)
         for (int i = lane; i < GRP_S; i += 64) a.weights_coarse[ray * GRP_S + i] = wc[i];
-      sample_pdf_merge_ray(S_.edgesC + g * (GRP_S + 1), wc, GRP_S, GRP_NI, a.u_fine ? a.u_fine + ray * GRP_NI : nullptr,
-                           S_.cdf[g], S_.vals[g], S_.edgesF + g * (GRP_SO + 1));
+      sample_pdf_merge_ray(FSN_SPAN(S_.edgesC, g * (GRP_S + 1), GRP_S + 1), wc, GRP_S, GRP_NI,
+                           a.u_fine ? a.u_fine + ray * GRP_NI : nullptr, FSN_AT(S_.cdf, g), FSN_AT(S_.vals, g),
+                           FSN_SPAN(S_.edgesF, g * (GRP_SO + 1), GRP_SO + 1));
     }
     lds_barrier();
   };
@@ -250,27 +254,27 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
       auto source = [&](int idx) {
         const int idc = min(idx, GRP_G * GRP_SO - 1);
         const int g = small_div(idc, GRP_SO), i = idc - g * GRP_SO;
-        return RaySrc{S_.rays + 6 * g, edges + g * (GRP_SO + 1) + i};
+        return RaySrc{FSN_SPAN(S_.rays, 6 * g, 6), edges + g * (GRP_SO + 1) + i};
       };
       if constexpr (NG == 1) {
         const int idx = slot(0);
         float sigma, rgb[3];
         mlp_tile<NT, PREC, true>(st, netF, source(idx), ring, sigma, rgb);
         if (lane < 16 && idx < GRP_G * GRP_SO) {
-          S_.sigF[idx] = sigma;
-          S_.rgbF[3 * idx + 0] = rgb[0];
-          S_.rgbF[3 * idx + 1] = rgb[1];
-          S_.rgbF[3 * idx + 2] = rgb[2];
+          FSN_AT(S_.sigF, idx) = sigma;
+          FSN_AT(S_.rgbF, 3 * idx + 0) = rgb[0];
+          FSN_AT(S_.rgbF, 3 * idx + 1) = rgb[1];
+          FSN_AT(S_.rgbF, 3 * idx + 2) = rgb[2];
         }
       } else {
         float sigma[2], rgb[2][3];
         mlp_tile2<NT, PREC, true>(st, netF, source(slot(0)), source(slot(1)), ring, sigma, rgb);
         const int q = (lane >> 4) & 1, idx = slot(q);
         if (lane < 32 && idx < GRP_G * GRP_SO) {
-          S_.sigF[idx] = sigma[q];
-          S_.rgbF[3 * idx + 0] = rgb[q][0];
-          S_.rgbF[3 * idx + 1] = rgb[q][1];
-          S_.rgbF[3 * idx + 2] = rgb[q][2];
+          FSN_AT(S_.sigF, idx) = sigma[q];
+          FSN_AT(S_.rgbF, 3 * idx + 0) = rgb[q][0];
+          FSN_AT(S_.rgbF, 3 * idx + 1) = rgb[q][1];
+          FSN_AT(S_.rgbF, 3 * idx + 2) = rgb[q][2];
         }
       }
     }
@@ -283,11 +287,12 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
       CompositeOut o{a.colors + 3 * ray, a.opacity + ray, a.depth + ray,
                      a.weights ? a.weights + ray * GRP_SO : nullptr, a.alphas ? a.alphas + ray * GRP_SO : nullptr,
                      a.trans ? a.trans + ray * GRP_SO : nullptr};
-      composite_ray(S_.sigF + g * GRP_SO, S_.rgbF + 3 * g * GRP_SO, eg, eg + 1, GRP_SO, true, a.bkgd[0], a.bkgd[1], a.bkgd[2], o);
+      composite_ray(FSN_SPAN(S_.sigF, g * GRP_SO, GRP_SO), FSN_SPAN(S_.rgbF, 3 * g * GRP_SO, 3 * GRP_SO), eg, eg + 1, GRP_SO,
+                    true, a.bkgd[0], a.bkgd[1], a.bkgd[2], o);
       if (a.sigmas)
-        for (int i = lane; i < GRP_SO; i += 64) a.sigmas[ray * GRP_SO + i] = S_.sigF[g * GRP_SO + i];
+        for (int i = lane; i < GRP_SO; i += 64) a.sigmas[ray * GRP_SO + i] = FSN_AT(S_.sigF, g * GRP_SO + i);
       if (a.rgbs)
-        for (int i = lane; i < 3 * GRP_SO; i += 64) a.rgbs[ray * GRP_SO * 3 + i] = S_.rgbF[3 * g * GRP_SO + i];
+        for (int i = lane; i < 3 * GRP_SO; i += 64) a.rgbs[ray * GRP_SO * 3 + i] = FSN_AT(S_.rgbF, 3 * g * GRP_SO + i);
       if (write_edges && a.edges_out)
         for (int i = lane; i <= GRP_SO; i += 64) a.edges_out[ray * (GRP_SO + 1) + i] = eg[i];
     }
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
       const int64_t r0 = grp * (int64_t)__builtin_amdgcn_readfirstlane(GRP_G);  // (G comes from LDS: keep r0 scalar)
       load_rays(r0);
       coarse_stage(r0);
-      fine_stage(r0, GRP_HIER ? S_.edgesF : S_.edgesC, true);
+      fine_stage(r0, GRP_HIER ? FSN_SPAN(S_.edgesF, 0, GRP_G * (GRP_SO + 1)) : FSN_SPAN(S_.edgesC, 0, GRP_G * (GRP_SO + 1)), true);
     }
   } else {
     // Two phases (frame-sized hierarchical launches): coarse pass + resampling of ALL groups of this workgroup, the
@@ -320,9 +325,9 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
         // (streaming: written once here, read once below, 494 MB per 800x800 frame - kept out of the way of the
         // weight streams the XCD's L2 is there for)
 #ifdef FSN_EDGES_PLAIN  // experiment: plain (L2 write-back) hand-over stores / loads
-        if (r0 + g < GRP_R) a.edges_out[(r0 + g) * (GRP_SO + 1) + i] = S_.edgesF[e];
+        if (r0 + g < GRP_R) a.edges_out[(r0 + g) * (GRP_SO + 1) + i] = FSN_AT(S_.edgesF, e);
 #else
-        if (r0 + g < GRP_R) __builtin_nontemporal_store(S_.edgesF[e], a.edges_out + (r0 + g) * (GRP_SO + 1) + i);
+        if (r0 + g < GRP_R) __builtin_nontemporal_store(FSN_AT(S_.edgesF, e), a.edges_out + (r0 + g) * (GRP_SO + 1) + i);
 #endif
       }
       lds_barrier();
@@ -346,13 +351,13 @@ __global__ __launch_bounds__(kThreads) void k_render_fused(RenderKArgs k) {
       for (int e = tid; e < GRP_G * (GRP_SO + 1); e += kThreads) {
         const int g = small_div(e, GRP_SO + 1), i = e - g * (GRP_SO + 1);
 #ifdef FSN_EDGES_PLAIN
-        S_.edgesF[e] = a.edges_out[min(r0 + g, GRP_R - 1) * (GRP_SO + 1) + i];
+        FSN_AT(S_.edgesF, e) = a.edges_out[min(r0 + g, GRP_R - 1) * (GRP_SO + 1) + i];
 #else
-        S_.edgesF[e] = __builtin_nontemporal_load(a.edges_out + min(r0 + g, GRP_R - 1) * (GRP_SO + 1) + i);
+        FSN_AT(S_.edgesF, e) = __builtin_nontemporal_load(a.edges_out + min(r0 + g, GRP_R - 1) * (GRP_SO + 1) + i);
 #endif
       }
       lds_barrier();
-      fine_stage(r0, S_.edgesF, false);
+      fine_stage(r0, FSN_SPAN(S_.edgesF, 0, GRP_G * (GRP_SO + 1)), false);
     }
   }
   st.drain();
@@ -560,4 +565,45 @@ extern "C" int fsn_bench_bare_stream(const fsn_mlp_desc* desc, int prec, const v
   else k_bare_stream<4><<<cus, kThreads, 0, s>>>(sp, (uint32_t)G.nph_density, layers, clock_out);
   FSN_LAUNCH_CHECK("k_bare_stream");
   return cus;
+}
+
+namespace fsn { int debug_report_occ(unsigned* host4); }  // render_occ.hip
+
+#ifdef FSN_DEBUG
+namespace fsn {
+// negative control of the debug build's checks: one deliberate out-of-range index and one out-of-range span
+__global__ void k_debug_selftest(int n) {
+  __shared__ float arr[32];
+  arr[threadIdx.x & 31] = 0.f;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    FSN_AT(arr, n) = 1.f;              // n = 32: one past the end
+    float* p = FSN_SPAN(arr, 30, 4);   // [30, 34) of 32
+    p[0] = 2.f;
+  }
+}
+}  // namespace fsn
+#endif
+
+extern "C" int fsn_debug_selftest(void) {
+#ifdef FSN_DEBUG
+  fsn::k_debug_selftest<<<1, 64>>>(32);
+  FSN_LAUNCH_CHECK("k_debug_selftest");
+  return FSN_OK;
+#else
+  FSN_REQUIRE(false, FSN_E_UNSUPPORTED, "fsn_debug_selftest: not a debug build");
+#endif
+}
+
+extern "C" int fsn_debug_report(uint32_t* out_host) {
+  FSN_REQUIRE(out_host, FSN_E_INVALID, "fsn_debug_report: null pointer");
+#ifdef FSN_DEBUG
+  FSN_HIP(hipDeviceSynchronize());
+  unsigned zero[4] = {0u, 0u, 0u, 0u};
+  FSN_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_dbg_render), sizeof(unsigned) * 4));
+  FSN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_render), zero, sizeof(zero)));
+  return fsn::debug_report_occ(out_host + 4);
+#else
+  FSN_REQUIRE(false, FSN_E_UNSUPPORTED, "fsn_debug_report: not a debug build (make -C fs-nerf_amd/csrc debug)");
+#endif
 }

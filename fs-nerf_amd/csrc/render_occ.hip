@@ -26,6 +26,9 @@
 
 namespace fsn {
 
+FSN_DEBUG_DEFINE_RECORD(g_dbg_occ)
+#define FSN_DEBUG_RECORD g_dbg_occ
+
 constexpr int kCap = 2048;      // samples of a batch (candidates; kept samples are a subset)
 constexpr int kMaxRays = 128;   // rays of a batch
 
@@ -170,13 +173,13 @@ __global__ __launch_bounds__(kThreads) void k_render_occ(OccKArgs k) {
         L = ray_lattice(S.G, o, d, a.near_plane, a.far_plane, a.step, a.u != nullptr, a.u ? a.u[ray] : 0.f);
         c = march_ray(S.G, a.bits, o, d, L, a.step, a.max_steps, [](float, float, bool, uint64_t, int) {});
       }
-      if (lane == 0) S.cnt[wave] = active ? c : -1;
+      if (lane == 0) FSN_AT(S.cnt, wave) = active ? c : -1;
       __syncthreads();
       // accept the chunk's rays in order while they fit (every thread evaluates the same recurrence)
       int nc = S.n_cand, nr = S.n_rays, my_off = -1, my_slot = 0, first_rej = kWaves;
       bool stop = false;
       for (int w = from; w < kWaves; ++w) {
-        const int cw = S.cnt[w];
+        const int cw = FSN_AT(S.cnt, w);
         if (cw < 0) continue;
         if (!stop && nr < kMaxRays && nc + cw <= kCap) {
           if (w == wave) { my_off = nc; my_slot = nr; }
@@ -196,16 +199,16 @@ __global__ __launch_bounds__(kThreads) void k_render_occ(OccKArgs k) {
       if (my_off >= 0) {
         if (lane == 0) {
 #pragma unroll
-          for (int q = 0; q < 3; ++q) { S.rays[6 * my_slot + q] = o[q]; S.rays[6 * my_slot + 3 + q] = d[q]; }
-          S.ray_id[my_slot] = ray;
-          S.cand_off[my_slot] = my_off;
-          S.cand_cnt[my_slot] = c;
+          for (int q = 0; q < 3; ++q) { FSN_AT(S.rays, 6 * my_slot + q) = o[q]; FSN_AT(S.rays, 6 * my_slot + 3 + q) = d[q]; }
+          FSN_AT(S.ray_id, my_slot) = ray;
+          FSN_AT(S.cand_off, my_slot) = my_off;
+          FSN_AT(S.cand_cnt, my_slot) = c;
         }
         march_ray(S.G, a.bits, o, d, L, a.step, a.max_steps, [&](float ts, float, bool keep, uint64_t m, int before) {
           if (keep) {
             const int pos = my_off + before + __popcll(m & ((1ull << lane) - 1ull));
-            S.t0c[pos] = ts;
-            S.slotc[pos] = (uint16_t)my_slot;
+            FSN_AT(S.t0c, pos) = ts;
+            FSN_AT(S.slotc, pos) = (uint16_t)my_slot;
           }
         });
       }
@@ -220,63 +223,63 @@ __global__ __launch_bounds__(kThreads) void k_render_occ(OccKArgs k) {
       for (int sub = 0; sub * 128 < n_cand; ++sub) {
         const int idx = sub * 128 + wave * 16 + (lane & 15);
         const int ic = min(idx, n_cand - 1);
-        const OccSrc src{S.rays + 6 * S.slotc[ic], S.t0c[ic], a.step};
+        const OccSrc src{FSN_SPAN(S.rays, 6 * FSN_AT(S.slotc, ic), 6), FSN_AT(S.t0c, ic), a.step};
         float sigma, rgb[3];
         st.begin_tile(nph_density);
         mlp_tile<NT, PREC, false>(st, net, src, ring, sigma, rgb);
-        if (lane < 16 && idx < n_cand) S.sigc[idx] = sigma;
+        if (lane < 16 && idx < n_cand) FSN_AT(S.sigc, idx) = sigma;
       }
       lds_barrier();
       // keep flags per ray: the arithmetic of k_visibility (occgrid.hip), one wave per ray
       for (int r = wave; r < n_rays; r += kWaves) {
-        const int Sn = S.cand_cnt[r], beg = S.cand_off[r];
+        const int Sn = FSN_AT(S.cand_cnt, r), beg = FSN_AT(S.cand_off, r);
         const int per = (Sn + 63) >> 6;
         const int i0 = lane * per, i1 = min(i0 + per, Sn);
         float lsum = 0.f;
-        for (int i = i0; i < i1; ++i) lsum += S.sigc[beg + i] * ((S.t0c[beg + i] + a.step) - S.t0c[beg + i]);
+        for (int i = i0; i < i1; ++i) lsum += FSN_AT(S.sigc, beg + i) * ((FSN_AT(S.t0c, beg + i) + a.step) - FSN_AT(S.t0c, beg + i));
         float tot;
         float run = wave_excl_scan(lsum, tot);
         int nk = 0;
         for (int i = i0; i < i1; ++i) {
-          const float sdt = S.sigc[beg + i] * ((S.t0c[beg + i] + a.step) - S.t0c[beg + i]);
+          const float sdt = FSN_AT(S.sigc, beg + i) * ((FSN_AT(S.t0c, beg + i) + a.step) - FSN_AT(S.t0c, beg + i));
           const float T = expf(-run), alpha = 1.0f - expf(-sdt);
           const bool kp = T >= a.early_stop_eps && alpha >= a.alpha_thre;
-          S.keepf[beg + i] = kp ? 1 : 0;
+          FSN_AT(S.keepf, beg + i) = kp ? 1 : 0;
           nk += kp ? 1 : 0;
           run += sdt;
         }
         int tk;
         wave_excl_scan_i(nk, tk);
-        if (lane == 0) S.kept_cnt[r] = tk;
+        if (lane == 0) FSN_AT(S.kept_cnt, r) = tk;
       }
     } else {
-      for (int i = tid; i < n_cand; i += kThreads) S.keepf[i] = 1;
-      for (int r = tid; r < n_rays; r += kThreads) S.kept_cnt[r] = S.cand_cnt[r];
+      for (int i = tid; i < n_cand; i += kThreads) FSN_AT(S.keepf, i) = 1;
+      for (int r = tid; r < n_rays; r += kThreads) FSN_AT(S.kept_cnt, r) = FSN_AT(S.cand_cnt, r);
     }
     lds_barrier();
     if (wave == 0) {  // exclusive scan of the kept counts over the batch's rays (<= 128: two per lane)
-      const int c0 = 2 * lane < n_rays ? S.kept_cnt[2 * lane] : 0, c1 = 2 * lane + 1 < n_rays ? S.kept_cnt[2 * lane + 1] : 0;
+      const int c0 = 2 * lane < n_rays ? FSN_AT(S.kept_cnt, 2 * lane) : 0, c1 = 2 * lane + 1 < n_rays ? FSN_AT(S.kept_cnt, 2 * lane + 1) : 0;
       int tot;
       const int ex = wave_excl_scan_i(c0 + c1, tot);
-      if (2 * lane < n_rays) S.kept_off[2 * lane] = ex;
-      if (2 * lane + 1 < n_rays) S.kept_off[2 * lane + 1] = ex + c0;
+      if (2 * lane < n_rays) FSN_AT(S.kept_off, 2 * lane) = ex;
+      if (2 * lane + 1 < n_rays) FSN_AT(S.kept_off, 2 * lane + 1) = ex + c0;
       if (lane == 0) S.n_kept = tot;
     }
     lds_barrier();
     for (int r = wave; r < n_rays; r += kWaves) {  // compaction, order preserved
-      const int Sn = S.cand_cnt[r], beg = S.cand_off[r], ko = S.kept_off[r];
+      const int Sn = FSN_AT(S.cand_cnt, r), beg = FSN_AT(S.cand_off, r), ko = FSN_AT(S.kept_off, r);
       const int per = (Sn + 63) >> 6;
       const int i0 = lane * per, i1 = min(i0 + per, Sn);
       int nk = 0;
-      for (int i = i0; i < i1; ++i) nk += S.keepf[beg + i];
+      for (int i = i0; i < i1; ++i) nk += FSN_AT(S.keepf, beg + i);
       int tk;
       int pos = ko + wave_excl_scan_i(nk, tk);
       for (int i = i0; i < i1; ++i) {
-        if (S.keepf[beg + i]) {
-          const float t0 = S.t0c[beg + i];
-          S.t0k[pos] = t0;
-          S.t1k[pos] = t0 + a.step;
-          S.slotk[pos] = (uint16_t)r;
+        if (FSN_AT(S.keepf, beg + i)) {
+          const float t0 = FSN_AT(S.t0c, beg + i);
+          FSN_AT(S.t0k, pos) = t0;
+          FSN_AT(S.t1k, pos) = t0 + a.step;
+          FSN_AT(S.slotk, pos) = (uint16_t)r;
           ++pos;
         }
       }
@@ -284,11 +287,11 @@ __global__ __launch_bounds__(kThreads) void k_render_occ(OccKArgs k) {
     lds_barrier();
     if (a.sample_t0) {  // sampler mode: the kept samples are the result
       for (int r = wave; r < n_rays; r += kWaves) {
-        const int64_t ray = S.ray_id[r];
-        const int ko = S.kept_off[r], Sk = S.kept_cnt[r];
-        for (int i = lane; i < Sk; i += 64) a.sample_t0[ray * a.sample_cap + i] = S.t0k[ko + i];
+        const int64_t ray = FSN_AT(S.ray_id, r);
+        const int ko = FSN_AT(S.kept_off, r), Sk = FSN_AT(S.kept_cnt, r);
+        for (int i = lane; i < Sk; i += 64) a.sample_t0[ray * a.sample_cap + i] = FSN_AT(S.t0k, ko + i);
         if (lane == 0) {
-          if (a.n_cand) a.n_cand[ray] = S.cand_cnt[r];
+          if (a.n_cand) a.n_cand[ray] = FSN_AT(S.cand_cnt, r);
           a.n_kept[ray] = Sk;
         }
       }
@@ -300,25 +303,26 @@ __global__ __launch_bounds__(kThreads) void k_render_occ(OccKArgs k) {
     for (int sub = 0; sub * 128 < n_kept; ++sub) {
       const int idx = sub * 128 + wave * 16 + (lane & 15);
       const int ic = min(idx, n_kept - 1);
-      const OccSrc src{S.rays + 6 * S.slotk[ic], S.t0k[ic], a.step};
+      const OccSrc src{FSN_SPAN(S.rays, 6 * FSN_AT(S.slotk, ic), 6), FSN_AT(S.t0k, ic), a.step};
       float sigma, rgb[3];
       st.begin_tile(nph_full);
       mlp_tile<NT, PREC, true>(st, net, src, ring, sigma, rgb);
       if (lane < 16 && idx < n_kept) {
-        S.sigk[idx] = sigma;
-        S.rgbk[3 * idx + 0] = rgb[0];
-        S.rgbk[3 * idx + 1] = rgb[1];
-        S.rgbk[3 * idx + 2] = rgb[2];
+        FSN_AT(S.sigk, idx) = sigma;
+        FSN_AT(S.rgbk, 3 * idx + 0) = rgb[0];
+        FSN_AT(S.rgbk, 3 * idx + 1) = rgb[1];
+        FSN_AT(S.rgbk, 3 * idx + 2) = rgb[2];
       }
     }
     lds_barrier();
     for (int r = wave; r < n_rays; r += kWaves) {
-      const int64_t ray = S.ray_id[r];
-      const int ko = S.kept_off[r], Sk = S.kept_cnt[r];
+      const int64_t ray = FSN_AT(S.ray_id, r);
+      const int ko = FSN_AT(S.kept_off, r), Sk = FSN_AT(S.kept_cnt, r);
       CompositeOut o{a.colors + 3 * ray, a.opacity + ray, a.depth + ray, nullptr, nullptr, nullptr};
-      composite_ray(S.sigk + ko, S.rgbk + 3 * ko, S.t0k + ko, S.t1k + ko, Sk, true, a.bkgd[0], a.bkgd[1], a.bkgd[2], o);
+      composite_ray(FSN_SPAN(S.sigk, ko, Sk), FSN_SPAN(S.rgbk, 3 * ko, 3 * Sk), FSN_SPAN(S.t0k, ko, Sk), FSN_SPAN(S.t1k, ko, Sk), Sk,
+                    true, a.bkgd[0], a.bkgd[1], a.bkgd[2], o);
       if (lane == 0) {
-        if (a.n_cand) a.n_cand[ray] = S.cand_cnt[r];
+        if (a.n_cand) a.n_cand[ray] = FSN_AT(S.cand_cnt, r);
         if (a.n_kept) a.n_kept[ray] = Sk;
       }
     }
@@ -336,6 +340,19 @@ static int launch_occ(const OccKArgs& k, int cus, hipStream_t s) {
   return FSN_OK;
 }
 
+}  // namespace fsn
+
+namespace fsn {
+int debug_report_occ(unsigned* host4) {  // (fsn_debug_report, render.hip)
+#ifdef FSN_DEBUG
+  unsigned zero[4] = {0u, 0u, 0u, 0u};
+  FSN_HIP(hipMemcpyFromSymbol(host4, HIP_SYMBOL(g_dbg_occ), sizeof(unsigned) * 4));
+  FSN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_occ), zero, sizeof(zero)));
+#else
+  for (int i = 0; i < 4; ++i) host4[i] = 0u;
+#endif
+  return FSN_OK;
+}
 }  // namespace fsn
 
 using namespace fsn;

@@ -70,6 +70,15 @@ typedef void* fsn_stream_t; /* hipStream_t */
                                    (an event of the delayed gradient scaling like a loss scaler's, not a range fallback) */
 
 int fsn_version(void);
+/* Debug build only (make -C fs-nerf_amd/csrc debug -> libfsnerf_hip_dbg.so, -DFSN_DEBUG): every index into the
+ * LDS arrays of k_render_fused / k_render_occ is range-checked; a violation is recorded and clamped, not trapped (GPU
+ * sanitizers are not available on this pool).  out_host: 8 uint32 = {violations, source line of the first, its index,
+ * the array's extent} for render.hip and for render_occ.hip; the records are cleared.  The release library returns
+ * FSN_E_UNSUPPORTED. */
+int fsn_debug_report(uint32_t* out_host);
+/* ... its negative control: a one-block launch with one deliberate out-of-range index and one out-of-range span into a
+ * 32-element LDS array (the next fsn_debug_report must say 2 violations, extent 32, for render.hip). */
+int fsn_debug_selftest(void);
 const char* fsn_last_error(void);
 /* number of compute units of the current device (grid sizing), or negative on error */
 int fsn_device_cus(void);
