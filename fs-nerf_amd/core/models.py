@@ -120,7 +120,8 @@ class _NerfTrainFn(torch.autograd.Function):
         # loss scaler's - and into this model's own accumulated word, which the host reads every `range_check_every`
         # training calls; it then warns and continues in bf16x3.
         if ctx.word is not None:
-            ops.step_flag(d_out.device).bitwise_or_(ctx.word)
+            for f in model._step_flags(d_out.device):
+                f.bitwise_or_(ctx.word)
             model._train_status(d_out.device)[0:1].bitwise_or_(ctx.word)
             model._train_calls += 1
             if model.range_check and model._train_calls % model.range_check_every == 0:
@@ -217,6 +218,22 @@ class NeRF(nn.Module):
             st = self._bwd_stage = (torch.ones(n, dtype=torch.float32, device=dev), torch.zeros(n, dtype=torch.int32, device=dev))
             self._bwd_calibrated = False
         return st
+
+    def _step_flags(self, dev):
+        """The step-flag words a training launch of this model reports into (device int32 [1] each): the word of every
+        gradient bucket that owns one of its parameters (`shard.FlatGrads.step_flag`, consumed by that bucket's
+        optimizer), and the device's shared word (`ops.step_flag`) for parameters no bucket owns."""
+        flags, loose = {}, False
+        for p in self.parameters():
+            f = getattr(p, "_fsn_step_flag", None)
+            if f is None or f.device != dev:
+                loose = True
+            else:
+                flags[id(f)] = f
+        out = list(flags.values())
+        if loose or not out:
+            out.append(ops.step_flag(dev))
+        return out
 
     def _train_status(self, dev) -> Tensor:
         """This model's accumulated training range words (device int32 [2]; OR of its calls' words since the last host

@@ -10,8 +10,8 @@ Differences from `torch.optim.Adam`, all deliberate:
   * a parameter whose gradient is None takes part with a ZERO gradient (its moments decay, torch skips it): the
     arenas are one flat buffer and one launch;
   * `zero_grad(set_to_none=True)` fills the gradient arena with zeros and keeps `p.grad` bound to it;
-  * a step in which an fp16-mode training launch overflowed is skipped on the device (`ops.step_flag`, or the flag
-    slot of an all-reduced bucket): parameters and moments untouched, and - round 4 - the step COUNTER too: it lives on
+  * a step in which an fp16-mode training launch on ITS parameters overflowed is skipped on the device (the gradient
+    bucket's own `step_flag` word, or the flag slot of an all-reduced bucket): parameters and moments untouched, and - round 4 - the step COUNTER too: it lives on
     the device (`fsn_adam_step_dev`), is advanced by the launch only when the update runs, and the bias corrections are
     formed from it there, so a skipped step is a step that did not happen, exactly as with torch's GradScaler
     (overflowing ACTIVATIONS: the model leaves fp16 mode at the host's next look; an overflowing GRADIENT under the
@@ -109,7 +109,7 @@ class FusedAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         self.arena.grads.bind()
         a = self.arena
-        flag = ops.step_flag(a.flat.device)
+        flag = a.grads.step_flag  # the word of THIS optimizer's parameters (shard.FlatGrads), not a per-device one
         with torch.cuda.device(a.flat.device):
             L.check(L.lib().fsn_adam_step_dev(ops._p(a.flat), ops._p(a.grads.flat), ops._p(self.exp_avg),
                                               ops._p(self.exp_avg_sq), a.numel, ops._p(self.step_count), ops._p(self._tick),

@@ -209,9 +209,10 @@ _step_flags: Dict[torch.device, Tensor] = {}
 
 
 def step_flag(device) -> Tensor:
-    """Per-device word of the CURRENT training step: every NeRF backward ORs its per-call range word into it (device
-    op), `FusedAdam.step` hands it to the Adam launch (bit 0 = some network overflowed fp16 in this step: the update
-    is skipped on the device) and clears it afterwards.  Never read by the host."""
+    """Per-device word of the current training step for parameters that NO gradient bucket owns (plain torch
+    optimizers): a NeRF backward ORs its per-call range word into it (device op).  Parameters in a `shard.FlatGrads`
+    bucket (`FusedAdam`) report into the bucket's own `step_flag` instead, which that optimizer hands to its
+    Adam launch (bit 0 / bit 2 set: the update is skipped on the device) and clears.  Never read by the host."""
     device = torch.device(device)
     if device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())

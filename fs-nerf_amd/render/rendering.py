@@ -324,7 +324,8 @@ def render_rays(rays_o: Tensor, rays_d: Tensor, estimator, model: nn.Module, tra
                     # per-layer scales (scaled fp16x3 inference) or switches to bf16x3.
                     word = torch.zeros(1, dtype=torch.int32, device=dev_)
                     edges = ops.sample_fused(model.packed(probe_s), rays_o, rays_d, status=word, **kw_s)
-                    ops.step_flag(dev_).bitwise_or_(word)
+                    for f_ in model._step_flags(dev_):
+                        f_.bitwise_or_(word)
                     model._train_status(dev_)[1:2].bitwise_or_(word)
                 else:
                     edges = model._guarded(dev_, "the sampler's density pass", probe_s,
@@ -347,7 +348,8 @@ def render_rays(rays_o: Tensor, rays_d: Tensor, estimator, model: nn.Module, tra
                 if needs_grad and f16 and model.range_check:
                     word = torch.zeros(1, dtype=torch.int32, device=dev_)
                     ray_indices, t_starts, t_ends = ops.occ_sample_fused(model.packed(probe_o), rays_o, rays_d, status=word, **kw_o)
-                    ops.step_flag(dev_).bitwise_or_(word)
+                    for f_ in model._step_flags(dev_):
+                        f_.bitwise_or_(word)
                     model._train_status(dev_)[1:2].bitwise_or_(word)
                 else:
                     ray_indices, t_starts, t_ends = model._guarded(

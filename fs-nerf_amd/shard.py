@@ -81,6 +81,11 @@ class FlatGrads:
         self._buf = torch.zeros(n + 1, dtype=torch.float32, device=dev)
         self.flat = self._buf[:n]
         self.flag_slot = self._buf[n:]
+        # THIS bucket's "a training launch of the current step overflowed" word (one word per device let model
+        # A's overflow skip optimizer B's update, and the first optimizer to step consumed the flag of the second): the
+        # backward of a network whose parameters live in this bucket ORs its per-call range word into it (device op),
+        # the optimizer that owns the bucket hands it to its Adam launch and clears it.
+        self.step_flag = torch.zeros(1, dtype=torch.int32, device=dev)
         self.bind()
 
     def view(self, i: int) -> torch.Tensor:
@@ -99,6 +104,7 @@ class FlatGrads:
                 v.copy_(g)
             p.grad = v
             p._fsn_grad_sink = True  # core/models.py: the backward kernels may accumulate into this buffer directly
+            p._fsn_step_flag = self.step_flag
 
     def zero(self) -> None:
         """`optimizer.zero_grad(set_to_none=False)` for the whole model in one fill."""
@@ -106,16 +112,15 @@ class FlatGrads:
         self.bind()
 
     def allreduce(self, average: bool = True, flag: Optional[float] = None) -> None:
-        """`flag`: this rank's "skip this step" value for the bucket's extra slot; default = the device's step flag
-        (ops.step_flag, raised by an fp16-mode training launch that overflowed) on the GPU, 0 on the CPU."""
+        """`flag`: this rank's "skip this step" value for the bucket's extra slot; default = the bucket's own step flag
+        (raised by an fp16-mode training launch on its parameters that overflowed)."""
         self.bind()
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
         if flag is not None:
             self.flag_slot.fill_(float(flag))
-        elif self._buf.is_cuda:  # this rank's step flag (device word of the training launches) into the bucket's slot
-            from . import ops
-            self.flag_slot.copy_((ops.step_flag(self._buf.device) & 5).to(torch.float32))  # FSN_STATUS_FP16_RANGE | _GRAD_RANGE
+        elif self._buf.is_cuda:  # this rank's step flag (word of the training launches on these parameters) into the slot
+            self.flag_slot.copy_((self.step_flag & 5).to(torch.float32))  # FSN_STATUS_FP16_RANGE | _GRAD_RANGE
         flat = self._buf
         if flat.is_cuda and dist.get_backend() == "gloo":  # CPU rehearsal backend: stage through host memory
             host = flat.cpu()

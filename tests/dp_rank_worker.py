@@ -58,7 +58,7 @@ def main():
         (rgb, _, _, _), _, _ = Rm.render_rays(o, d, est, m, train=True, white_bkgd=True, device=dev)
         torch.nn.functional.mse_loss(rgb, gt).backward()
         if step == 1 and rank == 1:
-            ops.step_flag(dev).fill_(1)  # what an overflowing fp16 training launch of this rank leaves behind
+            opt.grads.step_flag.fill_(1)  # what an overflowing fp16 training launch of this rank leaves behind
         opt.grads.allreduce(average=False)
         opt.step(grad_div=float(world))
         per_step_calls.append(calls["all_reduce"] - c0)

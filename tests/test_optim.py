@@ -128,7 +128,7 @@ def test_weight_norm_regulariser_matches_the_reference_formula(reg, arena):
 
 @pytest.mark.gpu
 def test_fused_adam_skips_a_flagged_step_and_checkpoints_its_state():
-    """(1) The device-side step flag (ops.step_flag: an fp16-mode training launch of this step overflowed) or the flag
+    """(1) The bucket's device-side step flag (FlatGrads.step_flag: an fp16-mode training launch of this step overflowed) or the flag
     slot of the all-reduced bucket makes the Adam launch a no-op - parameters and both moments untouched - and is
     consumed by the step.  (2) state_dict / load_state_dict carry the flat moments and the step count: a resumed
     optimizer continues bit for bit."""
@@ -153,14 +153,14 @@ def test_fused_adam_skips_a_flagged_step_and_checkpoints_its_state():
         opt.zero_grad()
         net(x).square().sum().backward()
         if which == "word":
-            ops.step_flag(dev).fill_(1)
+            opt.grads.step_flag.fill_(1)
         else:
             opt.grads.flag_slot.fill_(2.0)  # two ranks flagged
         opt.step()
         for p, b in zip(net.parameters(), before):
             assert torch.equal(p.detach(), b), f"{which}: a flagged step must not move the parameters"
         assert torch.equal(opt.exp_avg, m0) and torch.equal(opt.exp_avg_sq, v0), f"{which}: nor the moments"
-        assert int(ops.step_flag(dev).item()) == 0 and float(opt.grads.flag_slot.item()) == 0.0, "flag consumed"
+        assert int(opt.grads.step_flag.item()) == 0 and float(opt.grads.flag_slot.item()) == 0.0, "flag consumed"
         assert opt.steps == 1, f"{which}: a skipped step does not advance the (device-side) step counter"
     # ... so the bias corrections of the next clean step are those of step 2: the same update torch.optim.Adam makes when
     # a GradScaler withheld the two flagged steps (round 3 counted them on the host)

@@ -690,6 +690,37 @@ def test_training_range_guard_is_per_call_not_a_shared_sticky_word():
 
 
 @pytest.mark.gpu
+def test_two_optimizers_on_one_device_keep_their_step_flags_apart():
+    """the skip word was one per device - an overflow in model A skipped optimizer B's update, and the
+    first optimizer to step cleared the flag the second one needed.  The word now belongs to the gradient bucket: A's
+    overflowing step skips A's update only, B trains on, in either order of the two `step()` calls."""
+    from fs_nerf_amd import ops
+    from fs_nerf_amd.core.optim import FusedAdam
+    dev = torch.device("cuda:0")
+    N = 300
+    mk, sd_bad, sd_ok = _guard_nets(dev)
+    gen = torch.Generator().manual_seed(4)
+    x = (torch.rand(N, 3, generator=gen) * 2 - 1).to(dev)
+    d = torch.nn.functional.normalize(torch.randn(N, 3, generator=gen), dim=-1).to(dev)
+    c = torch.randn(N, 4, generator=gen).to(dev)
+    for first in ("good", "bad"):
+        good, bad = mk(sd_ok, "fp16x3"), mk(sd_bad, "fp16x3")
+        good.range_check_every = bad.range_check_every = 1000  # no host look during this test
+        og, ob = FusedAdam(good.parameters(), lr=1e-3), FusedAdam(bad.parameters(), lr=1e-3)
+        ops.step_flag(dev).zero_()
+        og.zero_grad(), ob.zero_grad()
+        (good(x, d) * c).sum().backward()
+        (bad(x, d) * c).nan_to_num(0.0, 0.0, 0.0).sum().backward()
+        assert int(ob.grads.step_flag.item()) & 1 and int(og.grads.step_flag.item()) == 0 and int(ops.step_flag(dev).item()) == 0
+        bg, bb = [p.detach().clone() for p in good.parameters()], [p.detach().clone() for p in bad.parameters()]
+        for o in ((og, ob) if first == "good" else (ob, og)):
+            o.step()
+        assert any(not torch.equal(p.detach(), b) for p, b in zip(good.parameters(), bg)), f"{first} first: the clean model trains"
+        assert all(torch.equal(p.detach(), b) for p, b in zip(bad.parameters(), bb)), f"{first} first: the flagged one is skipped"
+        assert og.steps == 1 and ob.steps == 0 and int(ob.grads.step_flag.item()) == 0
+
+
+@pytest.mark.gpu
 def test_training_sampler_overflow_joins_the_step_guard_without_a_host_read():
     """render_rays(train=True) with the hierarchical sampler: the sampler's density pass reports into a per-call word that
     is OR-ed into the step's guard on the device (no read-back between sampler and forward).  An overflowing pass makes
@@ -717,7 +748,7 @@ def test_training_sampler_overflow_joins_the_step_guard_without_a_host_read():
 
     before = [p.detach().clone() for p in m.parameters()]
     step()  # flagged on the device (sampler and forward both), not yet seen by the host
-    assert m.precision == "fp16x3" and int(ops.step_flag(dev).item()) & 1
+    assert m.precision == "fp16x3" and int(opt.grads.step_flag.item()) & 1 and int(ops.step_flag(dev).item()) == 0
     assert ops.range_ok(dev), "the training step does not touch the inference path's sticky word"
     opt.step()
     assert all(torch.equal(p.detach(), b) for p, b in zip(m.parameters(), before)), "a flagged step is skipped"
@@ -727,7 +758,7 @@ def test_training_sampler_overflow_joins_the_step_guard_without_a_host_read():
     opt.step()
     step()  # bf16x3: finite gradients, an update
     assert all(bool(torch.isfinite(p.grad).all()) for p in m.parameters())
-    assert int(ops.step_flag(dev).item()) == 0
+    assert int(ops.step_flag(dev).item()) == 0 and int(opt.grads.step_flag.item()) == 0
 
 
 @pytest.mark.gpu
