@@ -152,11 +152,13 @@ def round_e4m3_blocks(t: Tensor, block: int = 32) -> Tensor:
 def split_linear(h: Tensor, W: Tensor, scheme: str) -> Tensor:
     """h @ W.T as a split-precision matrix-core GEMM would form it (products exact, sums in h's dtype):
       "fp16x3"   ah.wh + 2^-11 (al'.wh + ah.wl'), low parts scaled by 2^11 (this build's parity mode, csrc/mlp_layout.hpp)
+      "fp16x3u"  ah.wh + al.wh + ah.wl with UNSCALED fp16 low parts (rounds 1-2; round 4's FSN_PREC_FP16X3U, which runs it
+                 on the network scaled by scale_state_dict so that every layer's activations sit at 2^4 .. 2^10)
       "bf16x3"   the same on bfloat16 parts, unscaled
       "fp16+f8"  ah.wh in fp16, the two correction products with every operand in block-scaled e4m3 (VERDICT r2 item 4:
                  a candidate mode, measured in tools/emulate_split.py and DESIGN.md 4.3; NOT built)"""
     fmt = "bf16" if scheme == "bf16x3" else "fp16"
-    K = 2048.0 if scheme == "fp16x3" else 1.0
+    K = 2048.0 if scheme == "fp16x3" else 1.0  # ("fp16x3u": unscaled low parts - meant for the SCALED network, below)
     ah, wh = round_to(h, fmt), round_to(W, fmt)
     ar, wr = h - ah, W - wh
     if scheme == "fp16+f8":
@@ -186,7 +188,7 @@ def nerf_forward(sd: Dict[str, Tensor], x: Tensor, dirs: Optional[Tensor], *,
     dt = x.dtype
     W = lambda k: sd[k].to(dt)
     q = lambda t: round_to(t, emulate)
-    if emulate in ("fp16x3", "bf16x3", "fp16+f8"):  # split-precision schemes (see split_linear)
+    if emulate in ("fp16x3", "fp16x3u", "bf16x3", "fp16+f8"):  # split-precision schemes (see split_linear)
         lin = lambda h, k: split_linear(h, W(k + ".weight"), emulate) + W(k + ".bias")
     else:
         lin = lambda h, k: q(h) @ q(W(k + ".weight")).T + W(k + ".bias")  # a matrix-core GEMM
@@ -205,6 +207,60 @@ def nerf_forward(sd: Dict[str, Tensor], x: Tensor, dirs: Optional[Tensor], *,
     f = torch.relu(lin(f, "branch"))
     rgb = torch.sigmoid(f @ W("rgb.weight").T + W("rgb.bias"))
     return torch.cat([rgb, sigma], dim=-1)
+
+
+# ---------------------------------------------------------------- the scaled network (round 4, FSN_PREC_FP16X3U)
+# Restatement of the packer's transformation (csrc/mlp_pack.hpp: fill_scales, pack_piece, aux_value) and of NeRF.calibrate
+# on state dicts: with a power of two s_g = 2^e_g per GEMM (hidden layers 0..L-1, connection, branch) the scaled network's
+# GEMM g produces s_g x the reference's activations and the same outputs (src/core/models.py:111-143), exactly.
+def layer_maxima(sd: Dict[str, Tensor], x: Tensor, dirs: Tensor, *, n_layers: int, skip: Sequence[int], n_freqs: int,
+                 n_freqs_dir: int, log_space: bool = True) -> list:
+    """Largest |output after its activation| of every GEMM over the samples (what fsn_mlp_layer_maxima reports)."""
+    W = lambda k: sd[k].double()
+    x_in = posenc(x.double(), n_freqs, log_space)
+    h, mx = x_in, []
+    for i in range(n_layers):
+        h = torch.relu(h @ W(f"layers.{i}.weight").T + W(f"layers.{i}.bias"))
+        mx.append(float(h.abs().max()))
+        if i in skip:
+            h = torch.cat([h, x_in], dim=-1)
+    f = h @ W("connection.weight").T + W("connection.bias")
+    mx.append(float(f.abs().max()))
+    f = torch.relu(torch.cat([f, posenc(dirs.double(), n_freqs_dir, log_space)], dim=-1) @ W("branch.weight").T + W("branch.bias"))
+    mx.append(float(f.abs().max()))
+    return mx
+
+
+def calibrate_exps(maxima: Sequence[float], target_exp: int = 10) -> list:
+    """e_g = target - ceil(log2 max_g): the layer's maximum lands in (2^(target-1), 2^target] (core/models.py:NeRF.calibrate)."""
+    import math
+    return [0 if v <= 0.0 else max(-60, min(60, target_exp - math.ceil(math.log2(v)))) for v in maxima]
+
+
+def scale_state_dict(sd: Dict[str, Tensor], exps: Sequence[int], *, n_layers: int, skip: Sequence[int], d_hidden: int) -> Dict[str, Tensor]:
+    """The network fsn_mlp_pack_scaled packs: weight columns fed by activations x s_g / s_(g-1), columns fed by an
+    encoding x s_g, biases x s_g, sigma.weight / s_(L-1), rgb.weight / s_branch (all powers of two: exact)."""
+    L, D = n_layers, d_hidden
+    out = {k: v.clone() for k, v in sd.items()}
+    p2 = lambda e: 2.0 ** e
+    for g in range(L):
+        w = out[f"layers.{g}.weight"]
+        if g == 0:
+            w *= p2(exps[0])
+        else:
+            w[:, :D] *= p2(exps[g] - exps[g - 1])
+            if (g - 1) in skip:
+                w[:, D:] *= p2(exps[g])
+        out[f"layers.{g}.bias"] *= p2(exps[g])
+    out["sigma.weight"] *= p2(-exps[L - 1])
+    out["connection.weight"] *= p2(exps[L] - exps[L - 1])
+    out["connection.bias"] *= p2(exps[L])
+    wb = out["branch.weight"]
+    wb[:, :D] *= p2(exps[L + 1] - exps[L])
+    wb[:, D:] *= p2(exps[L + 1])
+    out["branch.bias"] *= p2(exps[L + 1])
+    out["rgb.weight"] *= p2(-exps[L + 1])
+    return out
 
 
 def init_nerf_state_dict(n_layers: int, d_hidden: int, skip: Sequence[int], n_freqs: int,
