@@ -78,8 +78,8 @@ def test_plain_split_is_float32_grade_on_the_calibrated_network(s):
         f"float32 oracle {float(e32.max()):.2e} / {float(e32.quantile(0.99)):.2e} / {float(e32.mean()):.2e}"
     er, er32 = (emu[:, :3] - want[:, :3]).abs(), (o32[:, :3] - want[:, :3]).abs()
     assert float(er.max()) <= 4.0 * float(er32.max()) + 1e-7
-    if s != 1.0:
-        # the same arithmetic on the UNSCALED network: fp16 overflow above, subnormal low parts below
+    if s <= 1e-3 or s >= 1e6:
+        # the same arithmetic on the UNSCALED network: fp16 overflow above (hidden maxima ~3 s), subnormal low parts below
         raw = O.nerf_forward(sd, x, d, emulate="fp16x3u", **CFG).double()
         er_raw = ((raw[:, 3] - want[:, 3]).abs() / den)
         bad = (not bool(torch.isfinite(raw).all())) or float(er_raw.max()) > 10.0 * float(e32.max())
