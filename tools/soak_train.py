@@ -1,6 +1,8 @@
 """Soak of the training path (run ON the GPU box): three 8x256 students (plain, reference weight-norm regulariser l1 / l2)
 fitted for N iterations through render_rays(train=True) -> mse (+ reg) -> backward -> FusedAdam; records range warnings,
-steps skipped by the delayed gradient scaling, the per-stage factors it ended on -> gpurun_out/r03_soak.json.
+steps skipped by the delayed gradient scaling, the per-stage factors it ended on and (round 4) what the scaled fp16x3
+inference path of the sampler's density pass did on the way (calibrations, range events, final exponents, updates the
+optimizer applied) -> gpurun_out/r04_soak.json.
 usage: python tools/soak_train.py [iterations]"""
 import sys, os, warnings, json, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -59,6 +61,8 @@ for name, seed, alpha, norm in (("plain", 22, None, None), ("wnorm_l1", 23, 3e-8
     wmax = {k: float(v.detach().abs().max()) for k, v in student.named_parameters() if k.endswith("weight")}
     out[name] = {"precision_at_end": student.precision, "grad_overflow_looks": student.grad_overflow_looks,
                  "range_warnings": warned, "loss_first": losses[0], "loss_last": losses[-1], "stage_scale_log2": sc,
-                 "min_layer_max_weight": min(wmax.values())}
+                 "min_layer_max_weight": min(wmax.values()), "calibrations": student.calibrations,
+                 "range_events": student.range_events, "act_exps": student._act_exps, "act_target_exp": student.act_target_exp,
+                 "optimizer_steps_applied": opt.steps, "iterations": iters}
     print(name, json.dumps(out[name]), flush=True)
-json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r03_soak.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r04_soak.json"), "w"), indent=1)
