@@ -56,6 +56,9 @@ UB = 2048      # bytes per unit in the x3 stream layout
 D = int(os.environ.get("FSN_KLOOP_D", "2"))   # units of A operands in flight ahead of the MFMAs (D + 1 register sets)
 LEAD = D       # a phase is opened LEAD units before the previous one ends
 LOADS = 4     # LDS-DMA loads (1 KiB each) of a loader wave per phase: four loader waves x 4 KiB
+LOOK = int(os.environ.get("FSN_KLOOP_LOOK", "2"))  # phases staged ahead of the one being opened (mlp_dev.hpp kLook =
+# kNSlot - 2): a phase opening may leave (LOOK - 1) x LOADS loads of this wave in flight.  2 = the four-slot ring of the
+# product; 3 = a five-slot ring (experiment, with -DFSN_NSLOT=5 -DFSN_RING_EXPERIMENT)
 NSETS = D + 1  # A register sets
 SETS = {0: (240, 248), 1: (248, 240)}  # parity -> (first register of the current set, of the other set)
 CSET = 232     # first register of the correction set
@@ -112,7 +115,7 @@ def block(mode, nu, off, par):
             # the phase whose slot is restaged; then the loader waves issue their four 1-KiB LDS-DMA loads of the phase
             # after (FSN_KLOOP_ABL: timing experiments that drop parts of this - results are then garbage)
             if "nobarrier" not in ABL:
-                ins += [f"s_waitcnt vmcnt({LOADS})", "s_barrier"]
+                ins += [f"s_waitcnt vmcnt({(LOOK - 1) * LOADS})", "s_barrier"]
             if "nodma" not in ABL:
                 # only the loader waves (voff < 4 x 4096) issue LDS-DMA: the stall of issuing them then falls beside
                 # the MFMAs of their SIMD partners instead of on both waves at once (the predicate is taken from
