@@ -49,7 +49,9 @@ class OccRenderArgs(C.Structure):
                 ("colors", C.c_void_p), ("opacity", C.c_void_p), ("depth", C.c_void_p),
                 ("n_cand", C.c_void_p), ("n_kept", C.c_void_p), ("status", C.c_void_p), ("work_counter", C.c_void_p),
                 ("cam_pose", C.c_float * 12), ("cam_H", C.c_int32), ("cam_W", C.c_int32), ("cam_row0", C.c_int32),
-                ("cam_focal", C.c_double), ("sample_t0", C.c_void_p), ("sample_cap", C.c_int32)]
+                ("cam_focal", C.c_double), ("sample_t0", C.c_void_p), ("sample_cap", C.c_int32),
+                ("ex_weights", C.c_void_p), ("ex_alphas", C.c_void_p), ("ex_trans", C.c_void_p), ("ex_sigmas", C.c_void_p),
+                ("ex_rgbs", C.c_void_p)]
 
 
 _vp, _i, _i64, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
@@ -93,6 +95,7 @@ SIGNATURES = {
     "fsn_grad_scale": (_i, [_vp, _i64, _vp, _vp]),
     "fsn_occlusion_reg_bwd": (_i, [_vp, _i64, _vp, _i64, _f, _f, _i, _vp, _vp, _vp, _vp]),
     "fsn_occ_gather_samples": (_i, [_vp, _vp, _vp, _i, _i64, _f, _vp, _vp, _vp, _vp]),
+    "fsn_occ_gather_extras": (_i, [_vp, _vp, _vp, _i, _i64, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fsn_occgrid_march": (_i, [_vp, _vp, _i64, _vp, _i, _i, _vp, _f, _f, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fsn_packed_visibility": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _f, _f, _vp, _vp]),
     "fsn_occgrid_update": (_i, [_vp, _i64, _vp, _vp, _i64, _f, _vp, _vp, _vp]),

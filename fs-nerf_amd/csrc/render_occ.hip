@@ -285,7 +285,7 @@ __global__ __launch_bounds__(kThreads) void k_render_occ(OccKArgs k) {
       }
     }
     lds_barrier();
-    if (a.sample_t0) {  // sampler mode: the kept samples are the result
+    if (a.sample_t0 && !a.ex_weights) {  // sampler mode: the kept samples are the result
       for (int r = wave; r < n_rays; r += kWaves) {
         const int64_t ray = FSN_AT(S.ray_id, r);
         const int ko = FSN_AT(S.kept_off, r), Sk = FSN_AT(S.kept_cnt, r);
@@ -318,9 +318,19 @@ __global__ __launch_bounds__(kThreads) void k_render_occ(OccKArgs k) {
     for (int r = wave; r < n_rays; r += kWaves) {
       const int64_t ray = FSN_AT(S.ray_id, r);
       const int ko = FSN_AT(S.kept_off, r), Sk = FSN_AT(S.kept_cnt, r);
-      CompositeOut o{a.colors + 3 * ray, a.opacity + ray, a.depth + ray, nullptr, nullptr, nullptr};
+      // (EXTRAS mode: the per-sample weights / alphas / trans go straight into the ray's slot row)
+      const int64_t row = a.ex_weights ? ray * a.sample_cap : 0;
+      CompositeOut o{a.colors + 3 * ray, a.opacity + ray, a.depth + ray, a.ex_weights ? a.ex_weights + row : nullptr,
+                     a.ex_weights ? a.ex_alphas + row : nullptr, a.ex_weights ? a.ex_trans + row : nullptr};
       composite_ray(FSN_SPAN(S.sigk, ko, Sk), FSN_SPAN(S.rgbk, 3 * ko, 3 * Sk), FSN_SPAN(S.t0k, ko, Sk), FSN_SPAN(S.t1k, ko, Sk), Sk,
                     true, a.bkgd[0], a.bkgd[1], a.bkgd[2], o);
+      if (a.ex_weights) {
+        for (int i = lane; i < Sk; i += 64) {
+          a.sample_t0[row + i] = FSN_AT(S.t0k, ko + i);
+          a.ex_sigmas[row + i] = FSN_AT(S.sigk, ko + i);
+        }
+        for (int i = lane; i < 3 * Sk; i += 64) a.ex_rgbs[3 * row + i] = FSN_AT(S.rgbk, 3 * ko + i);
+      }
       if (lane == 0) {
         if (a.n_cand) a.n_cand[ray] = FSN_AT(S.cand_cnt, r);
         if (a.n_kept) a.n_kept[ray] = Sk;
@@ -372,9 +382,12 @@ extern "C" int fsn_render_rays_occgrid(const fsn_mlp_desc* desc, int prec, const
   if (rc != FSN_OK) return rc;
   if (a.R == 0) return FSN_OK;
   FSN_REQUIRE(blob && a.bits && a.work_counter, FSN_E_INVALID, "fsn_render_rays_occgrid: null pointer");
+  if (a.ex_weights)
+    FSN_REQUIRE(a.sample_t0 && a.ex_alphas && a.ex_trans && a.ex_sigmas && a.ex_rgbs && a.colors && a.opacity && a.depth,
+                FSN_E_INVALID, "fsn_render_rays_occgrid: the extras mode needs sample_t0, all five ex_* arrays and the per-ray outputs");
   if (a.sample_t0) {
     FSN_REQUIRE(a.n_kept && a.sample_cap >= a.max_steps, FSN_E_INVALID,
-                "fsn_render_rays_occgrid: the sampler mode needs n_kept and sample_cap >= max_steps");
+                "fsn_render_rays_occgrid: the sampler / extras mode needs n_kept and sample_cap >= max_steps");
   } else {
     FSN_REQUIRE(a.colors && a.opacity && a.depth, FSN_E_INVALID, "fsn_render_rays_occgrid: null output pointer");
   }
@@ -420,9 +433,13 @@ extern "C" int fsn_render_rays_occgrid(const fsn_mlp_desc* desc, int prec, const
 }
 
 namespace fsn {
+struct GatherEx {  // EXTRAS mode: slot rows -> packed arrays (weights, alphas, trans, sigmas; rgbs x3), or all null
+  const float* slot[5];
+  float* out[5];
+};
 __global__ void k_occ_gather(const int32_t* __restrict__ n_kept, const int64_t* __restrict__ offsets,
                              const float* __restrict__ t0s, int cap, int64_t R, float step, int64_t* __restrict__ ri,
-                             float* __restrict__ ts, float* __restrict__ te) {
+                             float* __restrict__ ts, float* __restrict__ te, GatherEx ex) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + wave;
   if (r >= R) return;
@@ -433,6 +450,12 @@ __global__ void k_occ_gather(const int32_t* __restrict__ n_kept, const int64_t* 
     ri[off + i] = r;
     ts[off + i] = t;
     te[off + i] = t + step;
+  }
+  if (ex.slot[0]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      for (int i = lane; i < n; i += 64) ex.out[k][off + i] = ex.slot[k][r * cap + i];
+    for (int i = lane; i < 3 * n; i += 64) ex.out[4][3 * off + i] = ex.slot[4][3 * r * cap + i];
   }
 }
 }  // namespace fsn
@@ -445,7 +468,26 @@ extern "C" int fsn_occ_gather_samples(const int32_t* n_kept, const int64_t* offs
   FSN_REQUIRE(n_kept && offsets && sample_t0 && ray_indices && t_starts && t_ends, FSN_E_INVALID,
               "fsn_occ_gather_samples: null pointer");
   k_occ_gather<<<(unsigned)((R + 3) / 4), 256, 0, as_stream(stream)>>>(n_kept, offsets, sample_t0, sample_cap, R, step,
-                                                                       ray_indices, t_starts, t_ends);
+                                                                       ray_indices, t_starts, t_ends, GatherEx{});
+  FSN_LAUNCH_CHECK("k_occ_gather");
+  return FSN_OK;
+}
+
+extern "C" int fsn_occ_gather_extras(const int32_t* n_kept, const int64_t* offsets, const float* sample_t0, int sample_cap,
+                                     int64_t R, float step, int64_t* ray_indices, float* t_starts, float* t_ends,
+                                     const float* const* slots, float* const* out, fsn_stream_t stream) {
+  FSN_REQUIRE(R >= 0 && sample_cap > 0, FSN_E_INVALID, "fsn_occ_gather_extras: bad sizes");
+  if (R == 0) return FSN_OK;
+  FSN_REQUIRE(n_kept && offsets && sample_t0 && ray_indices && t_starts && t_ends && slots && out, FSN_E_INVALID,
+              "fsn_occ_gather_extras: null pointer");
+  GatherEx ex;
+  for (int k = 0; k < 5; ++k) {
+    FSN_REQUIRE(slots[k] && out[k], FSN_E_INVALID, "fsn_occ_gather_extras: null slot / output array %d", k);
+    ex.slot[k] = slots[k];
+    ex.out[k] = out[k];
+  }
+  k_occ_gather<<<(unsigned)((R + 3) / 4), 256, 0, as_stream(stream)>>>(n_kept, offsets, sample_t0, sample_cap, R, step,
+                                                                       ray_indices, t_starts, t_ends, ex);
   FSN_LAUNCH_CHECK("k_occ_gather");
   return FSN_OK;
 }

@@ -827,10 +827,15 @@ def render_occ_fused(pm: PackedMLP, rays_o: Optional[Tensor], rays_d: Optional[T
                      levels: int, bits: Tensor, near_plane: float, far_plane: float, step: float, max_steps: int,
                      u: Optional[Tensor] = None, early_stop_eps: float = 1e-4, alpha_thre: float = 0.0,
                      bkgd=(0.0, 0.0, 0.0), pos_mask: Optional[Tensor] = None, dir_mask: Optional[Tensor] = None,
-                     camera=None, want_counts: bool = False):
+                     camera=None, want_counts: bool = False, want_extras: bool = False):
     """render_rays with the occupancy estimator in ONE launch (fsn_render_rays_occgrid): grid march -> density pass ->
     visibility cull -> full pass -> packed integration, no host sync.  -> colors [R,3], opacity [R,1], depth [R,1],
-    counts {"n_cand", "n_kept"} (int32 [R]) when asked for.  `camera` as in render_fused."""
+    counts {"n_cand", "n_kept"} (int32 [R]) when asked for.  `camera` as in render_fused.
+    `want_extras` (EXTRAS mode): the launch also leaves the kept samples' weights / alphas / trans / sigmas / rgbs and
+    interval starts in per-ray slot rows; behind an exclusive scan of the kept counts and ONE host read (the sample count
+    sizes the outputs) fsn_occ_gather_extras packs them: -> colors, opacity, depth, counts, (ray_indices int64 [N],
+    t_starts [N], t_ends [N], extras {weights, alphas, trans, sigmas [N], rgbs [N,3]}) - render_rays' full return
+    contract (rendering.py:88-107) from one launch + one gather."""
     if camera is not None:
         pose, cH, cW, cfocal, crow0, cnrows, dev = camera
         dev = torch.device(dev)
@@ -873,9 +878,17 @@ def render_occ_fused(pm: PackedMLP, rays_o: Optional[Tensor], rays_d: Optional[T
     depth = torch.empty(R, 1, device=dev)
     a.colors, a.opacity, a.depth = colors.data_ptr(), opacity.data_ptr(), depth.data_ptr()
     counts = {}
-    if want_counts:
+    if want_counts or want_extras:
         counts = {"n_cand": torch.zeros(R, dtype=torch.int32, device=dev), "n_kept": torch.zeros(R, dtype=torch.int32, device=dev)}
         a.n_cand, a.n_kept = counts["n_cand"].data_ptr(), counts["n_kept"].data_ptr()
+    slots = None
+    if want_extras:
+        cap = int(max_steps)
+        slots = {k: torch.empty(max(R, 1), cap, device=dev) for k in ("t0", "weights", "alphas", "trans", "sigmas")}
+        slots["rgbs"] = torch.empty(max(R, 1), cap, 3, device=dev)
+        a.sample_t0, a.sample_cap = slots["t0"].data_ptr(), cap
+        a.ex_weights, a.ex_alphas, a.ex_trans = slots["weights"].data_ptr(), slots["alphas"].data_ptr(), slots["trans"].data_ptr()
+        a.ex_sigmas, a.ex_rgbs = slots["sigmas"].data_ptr(), slots["rgbs"].data_ptr()
     # (one queue counter PER CALL - ADVICE r3: a per-device buffer let two launches on different streams race on it; the
     # launch zeroes it itself)
     wc = torch.empty(1, dtype=torch.int64, device=dev)
@@ -891,6 +904,21 @@ def render_occ_fused(pm: PackedMLP, rays_o: Optional[Tensor], rays_d: Optional[T
         if launch_timer is not None:
             e1.record()
             launch_timer.append((e0, e1))
+        if want_extras:
+            n_kept = counts["n_kept"]
+            incl = torch.cumsum(n_kept, 0, dtype=torch.int64)
+            N = int(incl[-1].item()) if R > 0 else 0  # the one host read: the sample count sizes the outputs
+            ri = torch.empty(N, dtype=torch.int64, device=dev)
+            ts, te = torch.empty(N, device=dev), torch.empty(N, device=dev)
+            ex = {k: torch.empty(N, device=dev) for k in ("weights", "alphas", "trans", "sigmas")}
+            ex["rgbs"] = torch.empty(N, 3, device=dev)
+            if N > 0:
+                order = ("weights", "alphas", "trans", "sigmas", "rgbs")
+                sp = (C.c_void_p * 5)(*[slots[k].data_ptr() for k in order])
+                op = (C.c_void_p * 5)(*[ex[k].data_ptr() for k in order])
+                L.check(L.lib().fsn_occ_gather_extras(_p(n_kept), _p(incl - n_kept), _p(slots["t0"]), int(max_steps), R, float(step),
+                                                      _p(ri), _p(ts), _p(te), sp, op, _stream()), "fsn_occ_gather_extras")
+            return colors, opacity, depth, counts, (ri, ts, te, ex)
     return colors, opacity, depth, counts
 
 

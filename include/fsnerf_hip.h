@@ -280,7 +280,7 @@ int fsn_bench_bare_stream(const fsn_mlp_desc* desc, int prec, const void* blob, 
  * rule and arithmetic as fsn_occgrid_march + fsn_mlp_fwd + fsn_packed_visibility + fsn_mlp_fwd +
  * fsn_composite_packed_fwd (the results are the unfused sequence's).  Outputs per ray only: colors [R,3], opacity [R],
  * depth [R] (what render_frame consumes, rendering.py:169-171), optional sample counts per ray n_cand / n_kept [R]
- * (int32; NULL to skip).  A caller that needs the packed per-sample extras uses the unfused entry points.
+ * (int32; NULL to skip); the per-sample extras of render_rays' full return contract in EXTRAS mode (below).
  *   aabb / res / levels / bits / near_plane / far_plane / step / u (one jitter value per ray or NULL) / max_steps as
  *   fsn_occgrid_march (max_steps <= 2048 here, else FSN_E_UNSUPPORTED); early_stop_eps / alpha_thre as
  *   fsn_packed_visibility (both <= 0: no density pass, every marched sample is kept);
@@ -317,6 +317,17 @@ typedef struct fsn_occ_render_args {
    * written and may be NULL.  fsn_occ_gather_samples packs the slots behind an exclusive scan of n_kept. */
   float* sample_t0;
   int32_t sample_cap;
+  /* EXTRAS mode (round 4; ex_weights != NULL, with sample_t0 / sample_cap / n_kept as above): render_rays' FULL return
+   * contract (rendering.py:88-107: (rgb, opacity, depth, extras), ray_indices, t_vals) in the one launch, without
+   * gradients.  The launch runs the full pass and the integration as usual (colors / opacity / depth are written) and
+   * additionally leaves, in per-ray slot rows of sample_cap entries, the kept samples' weights / alphas / trans / sigmas
+   * [R, sample_cap] and rgbs [R, sample_cap, 3] next to their interval starts in sample_t0; fsn_occ_gather_extras packs
+   * them behind an exclusive scan of n_kept into nerfacc's packed [N] arrays. */
+  float* ex_weights;
+  float* ex_alphas;
+  float* ex_trans;
+  float* ex_sigmas;
+  float* ex_rgbs;
 } fsn_occ_render_args;
 
 int fsn_render_rays_occgrid(const fsn_mlp_desc* desc, int prec, const void* blob, const fsn_occ_render_args* args_host,
@@ -327,6 +338,11 @@ int fsn_render_rays_occgrid(const fsn_mlp_desc* desc, int prec, const void* blob
 int fsn_occ_gather_samples(const int32_t* n_kept, const int64_t* offsets, const float* sample_t0, int sample_cap,
                            int64_t R, float step, int64_t* ray_indices, float* t_starts, float* t_ends,
                            fsn_stream_t stream);
+/* fsn_occ_gather_samples plus the EXTRAS mode's slot rows -> packed weights / alphas / trans / sigmas [N], rgbs [N,3]
+ * (slots / outputs in that order: HOST arrays of 5 DEVICE pointers). */
+int fsn_occ_gather_extras(const int32_t* n_kept, const int64_t* offsets, const float* sample_t0, int sample_cap, int64_t R,
+                          float step, int64_t* ray_indices, float* t_starts, float* t_ends,
+                          const float* const* slots_host_of_dev, float* const* out_host_of_dev, fsn_stream_t stream);
 
 /* ---- "next" rows ------------------------------------------------------------------ */
 
