@@ -144,7 +144,7 @@ CASES = {
 DIMS = {"4x128": (4, 128), "8x256": (8, 256)}
 
 
-def run_case(name, dev, precision, R=256, jitter=True, act_scaling=True):
+def run_case(name, dev, precision, R=192, jitter=True, act_scaling=True):
     from fs_nerf_amd.render import rendering as Rm
     tag, S, NI, two, rk, near, far, mr = CASES[name]
     if name == "C5":
@@ -175,9 +175,10 @@ def run_case(name, dev, precision, R=256, jitter=True, act_scaling=True):
     return hip, o32, truth
 
 
-@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5"])
-@pytest.mark.parametrize("jitter", [True, False])
-@pytest.mark.parametrize("act_scaling", [True, False])
+# (round 3's arithmetic - act_scaling False, what the training kernels run - on the headline and the NDC shape with jitter;
+# the default, scaled arithmetic on every shape with and without)
+@pytest.mark.parametrize("name,jitter,act_scaling", [(n, j, True) for n in ("C1", "C2", "C3", "C4", "C5") for j in (True, False)] +
+                         [("C3", True, False), ("C4", True, False), ("C1", False, False)])
 def test_end_to_end_fp16x3_is_float32_grade(dev, name, jitter, act_scaling):
     """The default parity mode on every BASELINE configuration's shape, end to end (for C3 / C4 that is coarse pass ->
     resampling -> fine pass on the kernel's own importance samples): error of the size of the float32 oracle's.  Both
@@ -234,7 +235,7 @@ def hidden_max(sd, x, L):
 
 
 @pytest.mark.parametrize("scale,factor,act_scaling", [(1e2, 3.0, True), (1e4, 3.0, True), (1e6, 3.0, True), (1e9, 3.0, True),
-                                                       (1e2, 3.0, False), (1e4, 3.0, False)])
+                                                       (1e4, 3.0, False)])
 def test_fp16x3_envelope_large_activations(dev, scale, factor, act_scaling):
     """Trained networks have activations far above the default initialisation's ~1: with hidden activations of 1e2
     and 1e4 (still inside the fp16 range) the parity mode must stay float32-grade (3 x the float32 oracle's error),
@@ -264,8 +265,8 @@ def test_fp16x3_envelope_large_activations(dev, scale, factor, act_scaling):
     assert_parity(hip, o32, truth, f"activations ~{scale:g}", factor=factor)
 
 
-@pytest.mark.parametrize("s,act_scaling", [(1e-1, True), (1e-2, True), (1e-3, True), (1e-4, True), (1e-6, True), (1e-9, True),
-                                           (1e-1, False), (1e-2, False), (1e-3, False), (1e-4, False)])
+@pytest.mark.parametrize("s,act_scaling", [(1e-2, True), (1e-4, True), (1e-6, True), (1e-9, True),
+                                           (1e-2, False), (1e-3, False), (1e-4, False)])
 def test_fp16x3_envelope_small_activations(dev, s, act_scaling):
     """The LOW end of the envelope (the reference's weight-norm regulariser pushes this way).
     Hidden activations ~ s x the default initialisation's.  Unscaled fp16 low parts are subnormal below ~0.1 (an
@@ -311,8 +312,8 @@ def test_fp16x3_envelope_small_activations(dev, s, act_scaling):
         assert fell_back, "below the envelope the mode must say so"
 
 
-@pytest.mark.parametrize("s,act_scaling", [(v, True) for v in (1e9, 1e6, 1e4, 1e2, 1.0, 1e-1, 1e-2, 1e-3, 1e-6, 1e-9)] +
-                         [(v, False) for v in (1e4, 1e2, 1.0, 1e-1, 1e-2, 1e-3)])
+@pytest.mark.parametrize("s,act_scaling", [(v, True) for v in (1e9, 1e6, 1e4, 1e2, 1.0, 1e-2, 1e-3, 1e-6, 1e-9)] +
+                         [(v, False) for v in (1e4, 1.0, 1e-3)])
 def test_fp16x3_sigma_relative_error_over_the_envelope(dev, s, act_scaling):
     """NeRF.forward alone, 20,000 points, the density head's RELATIVE error (a weight's error is of the same order):
     fp16x3 within 4 x the float32 oracle's error against a float64 evaluation over the whole native envelope
