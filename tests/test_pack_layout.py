@@ -231,6 +231,34 @@ def test_scaled_blob_is_the_same_network(golden_dir, tag, n_layers, d_hidden, pr
         pack_host(sd, n_layers, d_hidden, [4], 10, 4, prec, [61] + [0] * (n_layers + 1))
 
 
+@pytest.mark.parametrize("n_layers,d_hidden,skip,nf,nfd", [(6, 128, [1, 3], 7, 3), (2, 128, [0], 10, 4), (12, 256, [2, 5, 9], 10, 4)])
+def test_scaled_blob_other_topologies(n_layers, d_hidden, skip, nf, nfd):
+    """The scaling's column rules on other network shapes: several skip layers (their encoding columns take the layer's
+    own scale, their activation columns the ratio to the layer before), the shallowest network the kernels accept, a deep
+    one - scaled blob == the oracle's forward of the UNSCALED network, and == the oracle's own restatement of the
+    transformation (oracle.scale_state_dict) packed plainly."""
+    sd = O.init_nerf_state_dict(n_layers, d_hidden, skip, nf, nfd, seed=11)
+    rng = np.random.default_rng(n_layers)
+    exps = [int(e) for e in np.cumsum(rng.integers(0, 3, n_layers + 2)) + 2]
+    exps[n_layers] = exps[n_layers - 1] + 1
+    exps[n_layers + 1] = exps[n_layers] + 1
+    gen = torch.Generator().manual_seed(5)
+    x = torch.rand(16, 3, generator=gen) * 2 - 1
+    d = torch.nn.functional.normalize(torch.randn(16, 3, generator=gen), dim=-1)
+    ref = O.nerf_forward({k: v.double() for k, v in sd.items()}, x.double(), d.double(), n_layers=n_layers, skip=skip,
+                         n_freqs=nf, n_freqs_dir=nfd).numpy()
+    ones_p, ones_d = np.ones(64), np.ones(32)
+    emu = Emu(pack_host(sd, n_layers, d_hidden, skip, nf, nfd, 4, exps), 4)
+    y = emu.forward(x.numpy(), d.numpy(), ones_p, ones_d)
+    np.testing.assert_allclose(y, ref, rtol=0, atol=3e-6)
+    sds = O.scale_state_dict(sd, exps, n_layers=n_layers, skip=skip, d_hidden=d_hidden)
+    plain = pack_host(sds, n_layers, d_hidden, skip, nf, nfd, 4)
+    scaled = pack_host(sd, n_layers, d_hidden, skip, nf, nfd, 4, exps)
+    hw_p, hw_s = plain[:256].view(np.uint32).copy(), scaled[:256].view(np.uint32).copy()
+    hw_p[16:16 + n_layers + 2] = hw_s[16:16 + n_layers + 2]  # (the header records the exponents; everything else is equal)
+    assert np.array_equal(hw_p, hw_s) and np.array_equal(plain[256:], scaled[256:]), "packer's scaling == oracle.scale_state_dict"
+
+
 def test_blob_frequency_mask_and_wide_variants(golden_dir):
     # skip at two places + a frequency mask: emulator == oracle with the same mask
     sd = O.init_nerf_state_dict(6, 128, [1, 3], 7, 3, seed=7)
