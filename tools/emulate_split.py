@@ -7,6 +7,9 @@ products exact, sums in float32.  Schemes:
   fp16x3      a.w = ah.wh + al.wh + ah.wl, low part = fp16(v - high)                      (rounds 1-2 of this build)
   fp16x3s     the same with SCALED low parts, low' = fp16((v - high) * 2^11); the two correction products are summed in
               their own accumulator and folded in as 2^-11 * corr                          (round 3)
+  fp16x3+act  round 4 (FSN_PREC_FP16X3U): the fp16x3 arithmetic above on the SCALED network - per-layer powers of two,
+              calibrated on 512 other points so that every layer's largest activation lands in (2^9, 2^10], folded into
+              weights / biases / heads (oracle.layer_maxima / calibrate_exps / scale_state_dict: an exact transformation)
   bf16x3      the same three products on bfloat16 parts
   fp16+f8     ah.wh in fp16, the two correction products with every operand rounded to OCP e4m3 under a power-of-two
               scale per block of 32 k-values (v_mfma_scale_f32_16x16x128_f8f6f4's operand format): VERDICT r2 item 4
@@ -109,16 +112,23 @@ def main():
     gen = torch.Generator().manual_seed(0)
     x = torch.rand(a.points, 3, generator=gen) * 3.0 - 1.5
     d = torch.nn.functional.normalize(torch.randn(a.points, 3, generator=gen), dim=-1)
-    schemes = ["fp32", "fp16x3", "fp16x3s", "bf16x3", "fp16+f8", "fp16"]
+    schemes = ["fp32", "fp16x3", "fp16x3s", "fp16x3+act", "bf16x3", "fp16+f8", "fp16"]
+    gp = torch.Generator().manual_seed(9)
+    xp = torch.rand(512, 3, generator=gp) * 3.0 - 1.5
+    dp = torch.nn.functional.normalize(torch.randn(512, 3, generator=gp), dim=-1)
     rows = []
     print(f"{'s':>8} " + " ".join(f"{s + ' sig/rgb':>19}" for s in schemes))
-    for s in (1e4, 1e2, 1.0, 1e-1, 1e-2, 1e-3, 1e-4, 1e-5):
+    for s in (1e9, 1e6, 1e4, 1e2, 1.0, 1e-1, 1e-2, 1e-3, 1e-4, 1e-5, 1e-9):
         sd = make_sd(42, s)
         want = O.nerf_forward({k: v.double() for k, v in sd.items()}, x.double(), d.double(), **CFG)
         ws, wr = want[:, 3], want[:, :3]
         line, rec = f"{s:8.0e} ", {"s": s}
         for sc in schemes:
-            sg, rgb = forward(sd, x, d, sc)
+            if sc == "fp16x3+act":
+                exps = O.calibrate_exps(O.layer_maxima(sd, xp, dp, **CFG))
+                sg, rgb = forward(O.scale_state_dict(sd, exps, n_layers=L, skip=[4], d_hidden=D), x, d, "fp16x3")
+            else:
+                sg, rgb = forward(sd, x, d, sc)
             es = float(((sg.double() - ws).abs() / ws.abs().clamp_min(1e-2 * float(ws.abs().max()))).max())
             er = float((rgb.double() - wr).abs().max())
             rec[sc] = {"sigma_rel": es, "rgb_abs": er}
