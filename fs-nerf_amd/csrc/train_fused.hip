@@ -1252,7 +1252,11 @@ int fused_train_fwd(const fsn_mlp_desc* d, int prec, const float* const* W, cons
     case 3: return launch_fwd<4, 3>(a, grid, s);
     case 4: return launch_fwd<8, 0>(a, grid, s);
     case 5: return launch_fwd<8, 1>(a, grid, s);
+#ifdef FSN_EXP_TRAIN_ONEACC  // timing experiment (round 4): forward / backward in the one-accumulator arithmetic (results garbage)
+    case 6: return launch_fwd<8, 4>(a, grid, s);
+#else
     case 6: return launch_fwd<8, 2>(a, grid, s);
+#endif
     default: return launch_fwd<8, 3>(a, grid, s);
   }
 }
@@ -1299,7 +1303,11 @@ int fused_train_bwd(const fsn_mlp_desc* d, int prec, const float* const* W, int6
       case 3: rc = launch_bwd<4, 3>(a, grid, s); break;
       case 4: rc = launch_bwd<8, 0>(a, grid, s); break;
       case 5: rc = launch_bwd<8, 1>(a, grid, s); break;
+#ifdef FSN_EXP_TRAIN_ONEACC
+      case 6: rc = launch_bwd<8, 4>(a, grid, s); break;
+#else
       case 6: rc = launch_bwd<8, 2>(a, grid, s); break;
+#endif
       default: rc = launch_bwd<8, 3>(a, grid, s); break;
     }
     if (rc != FSN_OK) return rc;
