@@ -677,7 +677,7 @@ def other_workloads(args, dev, dist, backend):
 
     run("train", train_main, 20, 3, args.precision)
     run("occgrid", occ_main, 1, 1, args.precision)
-    run("train-occ", train_occ_main, 25, 5, args.precision)  # (the kept-sample count settles after a few optimizer steps)
+    run("train-occ", train_occ_main, 30, 5, args.precision)  # (round 3's run length: the kept-sample count - and with it the step time - falls as the network sharpens: 172 per ray after 8 steps, ~50 after 35, ~30 after 48)
 
     def frame(name, hw, s_, ni_, steps):
         try:
