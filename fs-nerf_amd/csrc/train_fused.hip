@@ -843,9 +843,18 @@ __global__ __launch_bounds__(64 * NW, 2) void k_wgrad(WgArgs a) {  // (2 waves p
         for (int ti = 0; ti < 2; ++ti) {
           acc[ti][bt] = mfma32<F16>(af[ti].hi, bfr[bt].hi, acc[ti][bt]);
           if (X3) {
-            acc[ti][bt] = mfma32<F16>(af[ti].lo, bfr[bt].hi, acc[ti][bt]);
+            // experiment switches (profiles/EXPERIMENTS_r4.md 11): bit 0 drops (dPre low) x (input high), bit 1 drops
+            // (dPre high) x (input low); _BIG for the 256x256 jobs only, _ALL for every job
+#ifndef FSN_EXP_WGRAD_DROP_BIG
+#define FSN_EXP_WGRAD_DROP_BIG 0
+#endif
+#ifndef FSN_EXP_WGRAD_DROP_ALL
+#define FSN_EXP_WGRAD_DROP_ALL 0
+#endif
+            constexpr int kDrop = FSN_EXP_WGRAD_DROP_ALL | ((MG == 4 && BT == 4) ? FSN_EXP_WGRAD_DROP_BIG : 0);
+            if constexpr (!(kDrop & 1)) acc[ti][bt] = mfma32<F16>(af[ti].lo, bfr[bt].hi, acc[ti][bt]);
 #ifndef FSN_WGRAD_NOBLO  // experiment: drop the (dPre high) x (input low) product
-            acc[ti][bt] = mfma32<F16>(F16 ? ahs[ti] : af[ti].hi, bfr[bt].lo, acc[ti][bt]);
+            if constexpr (!(kDrop & 2)) acc[ti][bt] = mfma32<F16>(F16 ? ahs[ti] : af[ti].hi, bfr[bt].lo, acc[ti][bt]);
 #endif
           }
         }
