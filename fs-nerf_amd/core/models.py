@@ -190,6 +190,7 @@ class NeRF(nn.Module):
         self._act_exps: Optional[list] = None   # n_layers + 2 exponents (kernel GEMM order), None = not calibrated
         self._calib_key = None                  # parameter versions the calibration was made with
         self._calib_moves = 0                   # target moves since then (same weights, data did not fit)
+        self._target_moved_by = 0               # ... and their sum: undone when the weights change
         self._needs_calibration = False
         self._calib_blob = None
         self.calibrations = 0                   # statistics: calibration launches / range events (fall-backs and
@@ -306,7 +307,13 @@ class NeRF(nn.Module):
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
         self._act_exps = None  # other weights: calibrate again on the next inference call
+        self._forget_target_moves()
         return out
+
+    def _forget_target_moves(self) -> None:
+        # target moves answered a probe that did not represent the data under the OLD weights
+        self.act_target_exp -= self._target_moved_by
+        self._target_moved_by = self._calib_moves = 0
 
     def _default_probe(self, dev):
         g = torch.Generator(device="cpu").manual_seed(0)
@@ -388,11 +395,13 @@ class NeRF(nn.Module):
             if self._calib_moves >= 3 or bits == (L.FSN_STATUS_FP16_RANGE | L.FSN_STATUS_FP16_SMALL):
                 return False
             self._calib_moves += 1
-            self.act_target_exp += -4 if bits & L.FSN_STATUS_FP16_RANGE else 3
+            move = -4 if bits & L.FSN_STATUS_FP16_RANGE else 3
+            self.act_target_exp += move
+            self._target_moved_by += move
             if not 2 <= self.act_target_exp <= 14:
                 return False
         else:
-            self._calib_moves = 0
+            self._forget_target_moves()
         try:
             self.calibrate(probe)
         except RuntimeError:

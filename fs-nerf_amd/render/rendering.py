@@ -393,6 +393,11 @@ def render_rays(rays_o: Tensor, rays_d: Tensor, estimator, model: nn.Module, tra
     return output, ray_indices, t_vals
 
 
+# A frame under the deferred range check is rendered at most this many times: every repeat follows a re-calibration (at
+# most three target moves per set of weights, NeRF._recalibrate) or the switch to bf16x3, which raises no flags.
+_FRAME_RERUNS = 6
+
+
 def _range_events(model, fine) -> int:
     """Range events (re-calibrations and fall-backs, NeRF.range_events) the frame's networks have seen so far."""
     return sum(m.range_events for m in {id(model): model, id(fine): fine}.values() if isinstance(m, NeRF))
@@ -437,11 +442,15 @@ def render_frame(hwf: Tuple[int, int, float], near: float, far: float, pose: Ten
         dev = torch.device(device)
         if dev.index is None:
             dev = torch.device("cuda", torch.cuda.current_device())
-        rgb, _, depth, _ = _fused_launch(None, None, (pose, H, W, focal, 0, H, dev), estimator, model, model_fine,
-                                         train, float(white_bkgd), None, None, False)
-        if _deferred_frame_flagged(model, fine, dev):  # (deferred range check: one look per frame)
-            rgb, _, depth, _ = _fused_launch(None, None, (pose, H, W, focal, 0, H, dev), estimator, model, model_fine,
-                                             train, float(white_bkgd), None, None, False)
+        cam = (pose, H, W, focal, 0, H, dev)
+        probe = lambda: _probe_on_rays(None, None, cam, *estimator.bounds())
+        for _ in range(_FRAME_RERUNS):
+            rgb, _, depth, _ = _fused_launch(None, None, cam, estimator, model, model_fine, train, float(white_bkgd), None,
+                                             None, False)
+            # deferred range check: one look per frame; a flagged frame is rendered again after the re-calibration on
+            # the frame's OWN rays (or the switch to bf16x3), and the repeat is looked at as well
+            if not _deferred_frame_flagged(model, fine, dev, probe=probe):
+                break
         return rgb.reshape(H, W, 3), depth.clamp(near, far).reshape(H, W)
     no_grad = not (torch.is_grad_enabled() and isinstance(fine, nn.Module) and fine.training)
     if no_grad and not ndc and _occ_fusable(estimator, model, model_fine, render_step_size):
@@ -450,9 +459,11 @@ def render_frame(hwf: Tuple[int, int, float], near: float, far: float, pose: Ten
         if dev.index is None:
             dev = torch.device("cuda", torch.cuda.current_device())
         cam = (pose, H, W, focal, 0, H, dev)
-        rgb, _, depth, _ = _fused_occ_launch(None, None, cam, estimator, model, train, float(white_bkgd), render_step_size)
-        if _deferred_frame_flagged(model, model, dev):
+        probe = lambda: _probe_in_box(None, None, cam, estimator.aabb)
+        for _ in range(_FRAME_RERUNS):
             rgb, _, depth, _ = _fused_occ_launch(None, None, cam, estimator, model, train, float(white_bkgd), render_step_size)
+            if not _deferred_frame_flagged(model, model, dev, probe=probe):
+                break
         return rgb.reshape(H, W, 3), depth.clamp(near, far).reshape(H, W)
     rays_o, rays_d = U.get_rays(pose, hwf, device)
     rays_o, rays_d = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
@@ -469,7 +480,13 @@ def render_frame(hwf: Tuple[int, int, float], near: float, far: float, pose: Ten
         (rgb, _, depth, _), *_ = out
         img.append(rgb)
         depth_map.append(depth)
-    if _deferred_frame_flagged(model, fine, img[0].device, events0):
+    if isinstance(estimator, OccGridEstimator):
+        probe = lambda: _probe_in_box(rays_o, rays_d, None, estimator.aabb)
+    elif isinstance(estimator, StratifiedEstimator):
+        probe = lambda: _probe_on_rays(rays_o, rays_d, None, *estimator.bounds())
+    else:
+        probe = None
+    if img and _deferred_frame_flagged(model, fine, img[0].device, events0, probe):
         # some chunk is invalid (this look, or an earlier chunk's flag consumed by the next chunk's poll) and the models
         # have been re-calibrated / switched to bf16x3: render the frame again
         return render_frame(hwf, near, far, pose, chunksize, estimator, model, train=train, ndc=ndc,

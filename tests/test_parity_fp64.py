@@ -561,6 +561,43 @@ def test_scaled_fp16x3_deferred_check_and_chunked_frames(dev):
     assert ops.range_poll(dev) == 0 and ops.range_ok(dev)
 
 
+def test_deferred_single_launch_frame_recalibrates_on_its_own_rays(dev):
+    """`render_frame` as ONE launch under the deferred range check, with a calibration that does not fit the frame: the
+    network's raw-position columns dominate layer 0 and the frame's rays reach 20,000 x the default probe's box, so the
+    scales measured on the default probe overflow at once.  The one look per frame finds the flag, re-calibrates on the
+    FRAME'S OWN rays (not on the default probe again, where three target moves would not have reached) and looks at the
+    repeat too: the frame that is returned is valid - equal, to float32 grade, to the frame of the synchronous guard."""
+    from fs_nerf_amd import ops
+    from fs_nerf_amd.render import rendering as Rm
+    L, D = 8, 256
+    sd = make_sd(L, D, 42)
+    sd["layers.0.weight"][:, :3] *= 64.0
+    # (a scene the float32 reference itself can render out there: a constant small density - a raw density of -1e5 over an
+    # interval of 625 is exp(+inf) in any arithmetic; make_sd's layers attenuate, so the colours do not saturate)
+    sd["sigma.weight"].zero_()
+    sd["sigma.bias"].fill_(0.002)
+    est = Rm.StratifiedEstimator(2.0, 40000.0, 64, 0)
+    hwf, pose = (24, 32, 30.0), torch.eye(4)
+    frame = lambda m_: Rm.render_frame(hwf, 2.0, 40000.0, pose, 1 << 20, est, m_, white_bkgd=True, device=dev)
+    m = hip_model(sd, L, D, dev, "fp16x3")
+    m.calibrate()  # default probe: positions in [-2, 2]^3
+    m.range_check = "deferred"
+    ref = hip_model(sd, L, D, dev, "fp16x3")  # synchronous guard: calibrates on the frame's rays in its first call
+    assert ops.range_poll(dev) == 0
+    with torch.no_grad():
+        with pytest.warns(RuntimeWarning, match="re-calibrated"):
+            img, depth = frame(m)
+        img_ref, depth_ref = frame(ref)
+    assert m.precision == "fp16x3" and ref.precision == "fp16x3" and m.range_events >= 1
+    assert bool(torch.isfinite(img).all()) and bool(torch.isfinite(depth).all()) and float(img.std()) > 0.02
+    assert torch.allclose(img, img_ref, rtol=1e-4, atol=2e-5) and torch.allclose(depth, depth_ref, rtol=1e-4, atol=1e-3)
+    assert ops.range_poll(dev) == 0 and ops.range_ok(dev)
+    # new weights forget the target moves the old ones needed
+    moved = m.act_target_exp
+    m.load_state_dict(make_sd(L, D, 43))
+    assert m.act_target_exp == m.ACT_TARGET_EXP and (moved == m.ACT_TARGET_EXP or m._target_moved_by == 0)
+
+
 # ------------------------------------------------------------------ BASELINE config 5: bf16 weights / activations
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
 def test_config5_single_pass_vs_rounding_emulating_oracle(dev, prec):
