@@ -59,6 +59,21 @@ import time
 
 import torch
 
+
+def _gc_quiet():
+    """Timed regions run without Python's cyclic collector, as `timeit` does: after the headline and the other workloads
+    the process holds enough objects that ONE generation-2 pass took 81-117 ms - inside a 150-ms timed region of 30
+    training steps it read as +3 ms per step (found with FSN_BENCH_DEBUG_STEPS=1; profiles/EXPERIMENTS_r4.md section 12).
+    The garbage is collected before the region instead."""
+    import gc
+    gc.collect()
+    gc.disable()
+
+
+def _gc_restore():
+    import gc
+    gc.enable()
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -270,11 +285,13 @@ def train_main(args, rank, world, dev, dist, backend):
     for _ in range(args.warmup):
         step()
     barrier()
+    _gc_quiet()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
+    _gc_restore()
     assert bool(torch.isfinite(loss))
     if world > 1:
         t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
@@ -352,11 +369,13 @@ def occ_main(args, rank, world, dev, dist, backend):
     for i in range(args.warmup):
         step(i, False)
     barrier()
+    _gc_quiet()
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(args.warmup + i, True)
     barrier()
     dt = time.perf_counter() - t0
+    _gc_restore()
     assert bool(torch.isfinite(out[0]).all()) and ops.range_ok(dev) and model.precision == args.precision
     if world > 1:
         t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
@@ -427,6 +446,7 @@ def train_occ_main(args, rank, world, dev, dist, backend):
     from fs_nerf_amd.utils import utilities as U
     model = init_sd(42)
     model.precision = args.precision
+    model.cull_precision = getattr(args, "cull_precision", None)
     model.to(dev).train()
     box = torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5])
     est = OccGridEstimator(roi_aabb=box, resolution=OCC_RES, levels=1).to(dev)
@@ -471,11 +491,34 @@ def train_occ_main(args, rank, world, dev, dist, backend):
         step(i)
     barrier()
     del kept[:]
+    dbg = os.environ.get("FSN_BENCH_DEBUG_STEPS")
+    ms0 = torch.cuda.memory_stats(dev) if dbg else None
+    if dbg:
+        import gc
+        gc_log, gc_t = [], [0.0]
+
+        def _gc_cb(phase, info):
+            if phase == "start":
+                gc_t[0] = time.perf_counter()
+            else:
+                gc_log.append((info["generation"], round((time.perf_counter() - gc_t[0]) * 1e3, 1), info["collected"]))
+        gc.callbacks.append(_gc_cb)
+    per = []
+    if not os.environ.get("FSN_BENCH_KEEP_GC"):
+        _gc_quiet()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        ts = time.perf_counter()
         loss = step(args.warmup + i)
+        per.append((time.perf_counter() - ts) * 1e3)
     barrier()
     dt = time.perf_counter() - t0
+    _gc_restore()
+    if dbg:  # host-side time of every step (no sync) and what the caching allocator did meanwhile
+        ms1 = torch.cuda.memory_stats(dev)
+        print("[debug] train-occ", model.cull_precision, "host ms per step", [round(v, 1) for v in per], {k: ms1[k] - ms0[k] for k in
+              ("num_device_alloc", "num_device_free", "num_alloc_retries", "allocation.all.allocated")}, "gc", gc_log, file=sys.stderr, flush=True)
+        gc.callbacks.remove(_gc_cb)
     assert bool(torch.isfinite(loss))
     if world > 1:
         t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
@@ -503,6 +546,7 @@ def train_occ_main(args, rank, world, dev, dist, backend):
                                    "estimator (128^3 cells, sphere of radius 1.477 occupied, held fixed), render_step_size 5e-3, "
                                    "one 8x256 NeRF (seed 42), MSE + fused Adam, update_every_n_steps on a second estimator",
                        "rays_per_step": T_RAYS, "marched_samples_per_ray": n_cand, "kept_samples_per_ray": n_kept,
+                       "cull_precision": model.cull_precision or "the model's (parity)",
                        "parallelism": f"dp{world} (ray-batch data parallel)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_TFLOPS, "traffic": None, "kernel": "whole step", "flop_per_ray": flop_per_ray},
@@ -662,13 +706,14 @@ def other_workloads(args, dev, dist, backend):
     from fs_nerf_amd.render import rendering as Rm
     out = {}
 
-    def run(name, fn, steps, warmup, precision):
-        a = types.SimpleNamespace(steps=steps, warmup=warmup, precision=precision)
+    def run(name, fn, steps, warmup, precision, **extra):
+        a = types.SimpleNamespace(steps=steps, warmup=warmup, precision=precision, **extra)
         try:
             line = fn(a, 0, 1, dev, dist, backend)
             out[name] = {"value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"],
                          "frac": line["roofline"]["frac"], "steps": steps, "dtype": precision, "metric": line["metric"]}
-            for k in ("marched_samples_per_ray", "kept_samples_per_ray", "unfused_sequence_ms", "fused_equals_unfused_bitwise"):
+            for k in ("marched_samples_per_ray", "kept_samples_per_ray", "unfused_sequence_ms", "fused_equals_unfused_bitwise",
+                      "cull_precision"):
                 if k in line["config"]:
                     out[name][k] = line["config"][k]
         except Exception as e:  # a failing side line must not take the headline down; it is recorded as such
@@ -678,6 +723,46 @@ def other_workloads(args, dev, dist, backend):
     run("train", train_main, 20, 3, args.precision)
     run("occgrid", occ_main, 1, 1, args.precision)
     run("train-occ", train_occ_main, 30, 5, args.precision)  # (round 3's run length: the kept-sample count - and with it the step time - falls as the network sharpens: 172 per ray after 8 steps, ~50 after 35, ~30 after 48)
+
+    # OPT-IN, not a parity mode (NeRF.cull_precision = "bf16": the visibility cull's density pass in single-pass bf16 as
+    # its own launch, everything it keeps in the model's mode): the same two workloads, with the image's deviation from
+    # the default path measured here
+    run("train-occ_cull-bf16", train_occ_main, 30, 5, args.precision, cull_precision="bf16")
+
+    def occ_frame_cull(name):
+        try:
+            from fs_nerf_amd.render.occgrid import OccGridEstimator
+            est = OccGridEstimator(roi_aabb=torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5]), resolution=OCC_RES, levels=1).to(dev)
+            ax = (torch.arange(OCC_RES) + 0.5) / OCC_RES * 3.0 - 1.5
+            x, y, z = torch.meshgrid(ax, ax, ax, indexing="ij")
+            est.set_binaries(((x * x + y * y + z * z).sqrt() < OCC_RADIUS)[None])
+            est.eval()
+            imgs, ms = {}, {}
+            for cull in (None, "bf16"):
+                m = init_sd(42)
+                with torch.no_grad():
+                    m.sigma.bias.add_(27.0)
+                m.precision, m.cull_precision = args.precision, cull
+                m.to(dev).eval()
+                with torch.no_grad():
+                    for i in range(2):  # (the second frame is the timed one)
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        imgs[cull] = Rm.render_frame((H, W, FOCAL), NEAR, FAR, orbit_pose(4.0), 1 << 30, est, m, white_bkgd=True,
+                                                     render_step_size=OCC_STEP, device=dev)
+                        torch.cuda.synchronize()
+                        ms[cull] = (time.perf_counter() - t0) * 1e3
+            out[name] = {"value": H * W / (ms["bf16"] * 1e-3), "unit": "rays/s", "ms_per_step": ms["bf16"], "steps": 1,
+                         "dtype": f"{args.precision}, cull bf16", "default_path_ms_same_frame": ms[None],
+                         "max_abs_rgb_vs_default": float((imgs["bf16"][0] - imgs[None][0]).abs().max()),
+                         "max_abs_depth_vs_default": float((imgs["bf16"][1] - imgs[None][1]).abs().max()),
+                         "metric": "rendered rays/sec (occupancy-grid estimator frame of `occgrid`, opt-in bf16 visibility cull: "
+                                   "sampler launch + full pass + integration)"}
+        except Exception as e:
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.synchronize()
+
+    occ_frame_cull("occgrid_cull-bf16")
 
     def frame(name, hw, s_, ni_, steps):
         try:
@@ -692,12 +777,14 @@ def other_workloads(args, dev, dist, backend):
                 Rm.render_frame((hw, hw, focal), NEAR, FAR, orbit_pose(0.0), 1 << 30, est, coarse, white_bkgd=True, device=dev, model_fine=fine)
                 torch.cuda.synchronize()
                 del ev[:]
+                _gc_quiet()
                 t0 = time.perf_counter()
                 for i in range(steps):
                     rgb, _ = Rm.render_frame((hw, hw, focal), NEAR, FAR, orbit_pose(4.0 * (i + 1)), 1 << 30, est, coarse,
                                              white_bkgd=True, device=dev, model_fine=fine)
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
+                _gc_restore()
             kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
             ops.launch_timer = None
             assert bool(torch.isfinite(rgb).all())
@@ -725,6 +812,8 @@ def main():
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the in-process train / occgrid / train-occ / bf16 lines")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="N>1: every rank its own frames (weak), or row blocks of the same frame (strong)")
+    ap.add_argument("--cull-precision", choices=("bf16",), default=None,
+                    help="train-occ: NeRF.cull_precision (opt-in single-pass density pass of the visibility cull; not a parity mode)")
     ap.add_argument("--extras", action="store_true", help="also write the per-sample outputs (weights, ...) in the timed launch")
     ap.add_argument("--raw-launch", action="store_true",
                     help="time ops.render_fused directly instead of the product path render_frame (A/B of the host path)")
@@ -820,11 +909,13 @@ def main():
     barrier()
     events0 = coarse.range_events + fine.range_events
     ops.clock_buffer = clock_buf
+    _gc_quiet()
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(args.warmup + i, True)
     barrier()
     dt = time.perf_counter() - t0
+    _gc_restore()
     ops.clock_buffer = None
     assert bool(torch.isfinite(out[0]).all())
     assert ops.range_ok(dev), "an fp16-mode launch reported activations outside the fp16 range"

@@ -184,6 +184,13 @@ class NeRF(nn.Module):
         self.dir_mask: Optional[Tensor] = None
         self._packed = None
         self._packed_key = None
+        # OPT-IN, not a parity mode: arithmetic of the density pass behind the occupancy estimator's visibility cull when
+        # it runs as the sampler in front of a training forward (None = the model's inference mode; "bf16" = one pass).
+        # That pass only decides which marched samples are KEPT (transmittance >= early_stop_eps); the kept samples are
+        # then evaluated, integrated and differentiated in the model's own mode.  See `packed_cull`.
+        self.cull_precision: Optional[str] = None
+        self._packed_cull = None
+        self._packed_cull_key = None
         # per-layer activation scaling of the fp16x3 inference path (module docstring)
         self.act_scaling = True
         self.act_target_exp = self.ACT_TARGET_EXP
@@ -454,6 +461,21 @@ class NeRF(nn.Module):
             self._packed.pack(ws, bs, exps)
             self._packed_key = key
         return self._packed
+
+    def packed_cull(self) -> ops.PackedMLP:
+        """The weights packed for the mode `cull_precision` names (single-pass bf16: float32's range, no calibration and
+        no range flags), re-packed when a parameter changed."""
+        if self.cull_precision != "bf16":
+            raise ValueError("NeRF.cull_precision: None or 'bf16'")
+        ws, bs = self._tensors()
+        key = (self.cull_precision, ws[0].device) + self._param_key()
+        if self._packed_cull is None or key != self._packed_cull_key:
+            desc = ops.make_desc(self.n_layers, self.d_hidden, self.skip, self.pos_encoder.freqs, self.dir_encoder.freqs)
+            if self._packed_cull is None or self._packed_cull.blob.device != ws[0].device:
+                self._packed_cull = ops.PackedMLP(desc, self.PRECISIONS[self.cull_precision], ws[0].device)
+            self._packed_cull.pack(ws, bs)
+            self._packed_cull_key = key
+        return self._packed_cull
 
     def _mask(self, m: Optional[Tensor], dev) -> Optional[Tensor]:
         return None if m is None else m.to(dev, torch.float32)

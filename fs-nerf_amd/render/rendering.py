@@ -283,11 +283,13 @@ def render_rays(rays_o: Tensor, rays_d: Tensor, estimator, model: nn.Module, tra
     # each differentiable where the reference's is
     fused = isinstance(estimator, StratifiedEstimator) and isinstance(model, NeRF) and \
         (model_fine is None or isinstance(model_fine, NeRF)) and not needs_grad
-    if not needs_grad and not want_extras and _occ_fusable(estimator, model, model_fine, render_step_size):
+    # (NeRF.cull_precision, opt-in: the cull's density pass runs as its own launch in that mode - the sampler branch below)
+    own_cull = isinstance(model, NeRF) and model.cull_precision is not None
+    if not needs_grad and not want_extras and not own_cull and _occ_fusable(estimator, model, model_fine, render_step_size):
         # frame rendering with the occupancy estimator (only rgb / depth are consumed, rendering.py:169-171): one launch
         rgb, opacity, depth, _ = _fused_occ_launch(rays_o, rays_d, None, estimator, model, train, bk, render_step_size)
         return (rgb, opacity, depth, {}), None, None
-    if not needs_grad and want_extras and FUSED_OCC_EXTRAS and _occ_fusable(estimator, model, model_fine, render_step_size) and \
+    if not needs_grad and want_extras and not own_cull and FUSED_OCC_EXTRAS and _occ_fusable(estimator, model, model_fine, render_step_size) and \
             rays_o.shape[0] * estimator.max_steps(render_step_size) <= FUSED_OCC_EXTRAS_MAX_SLOTS:
         # the reference's FULL return contract (rendering.py:88-107) through the occupancy estimator without gradients:
         # ONE launch (the extras mode of fsn_render_rays_occgrid) + one gather behind one host read - round 3 took the
@@ -343,7 +345,7 @@ def render_rays(rays_o: Tensor, rays_d: Tensor, estimator, model: nn.Module, tra
                     edges = model._guarded(dev_, "the sampler's density pass", probe_s,
                                            lambda: ops.sample_fused(model.packed(probe_s), rays_o, rays_d, **kw_s))
                 ray_indices, t_starts, t_ends = ops.edges_to_packed(edges)
-        elif FUSED_OCC_SAMPLER and rays_o.shape[0] >= max(1, FUSED_OCC_SAMPLER_MIN_RAYS) and \
+        elif FUSED_OCC_SAMPLER and (rays_o.shape[0] >= max(1, FUSED_OCC_SAMPLER_MIN_RAYS) or own_cull) and \
                 _occ_fusable(estimator, model, None, render_step_size):
             # estimator.sampling(..., sigma_fn) of the reference's training step (rendering.py:66-74) as one launch + one
             # gather (ops.occ_sample_fused): the same samples bit for bit as march -> density pass -> visibility ->
@@ -357,7 +359,10 @@ def render_rays(rays_o: Tensor, rays_d: Tensor, estimator, model: nn.Module, tra
             f16 = model.fp16_family(model.PRECISIONS[model.precision])
             probe_o = lambda: _probe_in_box(rays_o, rays_d, None, estimator.aabb)
             with torch.no_grad():
-                if needs_grad and f16 and model.range_check:
+                if model.cull_precision is not None:
+                    # opt-in (NeRF.cull_precision): the cull's density pass in single-pass bf16 - no range flags to guard
+                    ray_indices, t_starts, t_ends = ops.occ_sample_fused(model.packed_cull(), rays_o, rays_d, **kw_o)
+                elif needs_grad and f16 and model.range_check:
                     word = torch.zeros(1, dtype=torch.int32, device=dev_)
                     ray_indices, t_starts, t_ends = ops.occ_sample_fused(model.packed(probe_o), rays_o, rays_d, status=word, **kw_o)
                     for f_ in model._step_flags(dev_):
@@ -453,7 +458,8 @@ def render_frame(hwf: Tuple[int, int, float], near: float, far: float, pose: Ten
                 break
         return rgb.reshape(H, W, 3), depth.clamp(near, far).reshape(H, W)
     no_grad = not (torch.is_grad_enabled() and isinstance(fine, nn.Module) and fine.training)
-    if no_grad and not ndc and _occ_fusable(estimator, model, model_fine, render_step_size):
+    own_cull = isinstance(model, NeRF) and model.cull_precision is not None  # (opt-in: sampler launch + full pass, render_rays)
+    if no_grad and not ndc and not own_cull and _occ_fusable(estimator, model, model_fine, render_step_size):
         # the reference's own frame path (occupancy estimator): ONE launch, rays generated inside it
         dev = torch.device(device)
         if dev.index is None:

@@ -243,3 +243,50 @@ def test_fused_occupancy_extras_mode_is_the_full_return_contract(dev, net, res, 
     with torch.no_grad():
         (rgb_e, op_e, dep_e, ex_e), ri_e, tv_e = Rm.render_rays(o, d, empty, m, white_bkgd=True, render_step_size=step, device=dev)
     assert ri_e.numel() == 0 and tv_e.numel() == 0 and ex_e["rgbs"].shape == (0, 3) and bool((rgb_e == 1.0).all())
+
+
+@pytest.mark.parametrize("gain,shift", [(64.0, 3.0), (512.0, 30.0)])
+def test_opt_in_bf16_cull_differs_from_the_default_only_at_the_threshold(dev, gain, shift):
+    """`NeRF.cull_precision = "bf16"` (opt-in, NOT a parity mode): the density pass behind the estimator's visibility cull
+    runs in single-pass bf16 as its own launch; what it keeps is evaluated, integrated and differentiated in the model's own
+    mode.  What may differ from the default is therefore WHICH samples sit next to the cull's threshold (transmittance 1e-4):
+    every sample only one of the two kept has a transmittance within a factor 2 of it, such samples are a small fraction,
+    and rgb / opacity / depth move by far less than the threshold itself.  The same holds with gradients."""
+    from fs_nerf_amd.render import rendering as Rm
+    step, eps = 1e-2, 1e-4
+    est = sphere_grid(64, 1, dev)
+    o, d = orbit_rays(2000, 9)
+    m0, m1 = make_model(8, 256, 4, dev, gain=gain, shift=shift), make_model(8, 256, 4, dev, gain=gain, shift=shift)
+    m1.cull_precision = "bf16"
+    run = lambda m_, **kw: Rm.render_rays(o, d, est, m_, white_bkgd=True, render_step_size=step, device=dev, **kw)
+    with torch.no_grad():
+        (rgb0, op0, dep0, ex0), ri0, tv0 = run(m0)
+        (rgb1, op1, dep1, ex1), ri1, tv1 = run(m1)
+        (rgb1f, _, dep1f, _), _, _ = run(m1, want_extras=False)
+    assert torch.equal(rgb1f, rgb1) and torch.equal(dep1f, dep1)
+    assert float((rgb1 - rgb0).abs().max()) < 5e-5 and float((op1 - op0).abs().max()) < 5e-5 and float((dep1 - dep0).abs().max()) < 5e-4
+    # the kept sets as (ray, lattice index) pairs
+    key = lambda ri, tv: set(zip(ri.tolist(), torch.round(tv / step * 4).long().tolist()))
+    k0, k1 = key(ri0, tv0), key(ri1, tv1)
+    only0, only1 = k0 - k1, k1 - k0
+    assert len(k0) > 20000 and len(only0) + len(only1) <= 0.01 * len(k0), (len(k0), len(only0), len(only1))
+    for ks, ri, tv, ex in ((only0, ri0, tv0, ex0), (only1, ri1, tv1, ex1)):
+        if not ks:
+            continue
+        keys = list(zip(ri.tolist(), torch.round(tv / step * 4).long().tolist()))
+        T = torch.tensor([float(ex["trans"][i]) for i, k_ in enumerate(keys) if k_ in ks])
+        assert float(T.min()) > eps / 2 and float(T.max()) < eps * 2, (float(T.min()), float(T.max()))
+    # training step: gradients through the kept samples
+    grads = []
+    for m_ in (m0, m1):
+        m_.train()
+        est.train()
+        est.generator = torch.Generator(device=dev).manual_seed(5)
+        (rgb, _, _, _), _, _ = Rm.render_rays(o, d, est, m_, train=True, white_bkgd=True, render_step_size=step, device=dev)
+        rgb.square().mean().backward()
+        grads.append({n: p.grad.clone() for n, p in m_.named_parameters()})
+        m_.eval()
+    est.eval()
+    for n in grads[0]:
+        a, b = grads[0][n], grads[1][n]
+        assert bool(torch.isfinite(b).all()) and float((a - b).abs().max()) <= 2e-3 * float(a.abs().max()) + 1e-12, n

@@ -201,6 +201,40 @@ def test_packed_occupancy_path_on_trained_weights(dev, students, which):
     STATS.setdefault("packed", {})[f"{which}_samples_per_ray"] = float(ri.numel()) / R
 
 
+@pytest.mark.parametrize("which", ["plain", "wnorm_l1", "wnorm_l2"])
+def test_opt_in_bf16_cull_on_trained_weights(dev, students, which):
+    """`NeRF.cull_precision = "bf16"` (opt-in: the visibility cull's density pass in single-pass bf16, the kept samples in
+    the model's own mode) on the trained students, through the grid their own densities produce: rgb / opacity / depth
+    within 5e-5 of the default path's (the cull's own threshold is a transmittance of 1e-4), kept sets that differ in
+    under 1 % of their samples."""
+    from fs_nerf_amd.render import rendering as Rm
+    from fs_nerf_amd.render.occgrid import OccGridEstimator
+    sd = students[which]
+    m0, m1 = hip_model(sd, L, D, dev, "fp16x3"), hip_model(sd, L, D, dev, "fp16x3")
+    m1.cull_precision = "bf16"
+    step = 1e-2
+    est = OccGridEstimator(roi_aabb=torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5]), resolution=32, levels=1).to(dev).train()
+    est.generator = torch.Generator(device=dev).manual_seed(5)
+    with torch.no_grad():
+        est.update_every_n_steps(step=0, occ_eval_fn=lambda x: m0(x) * step, occ_thre=1e-2)
+    est.eval()
+    R = 2048
+    o, d, _ = orbit_rays(R, 9, 800, 0.5 * 800 / np.tan(0.5 * 0.6911112))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        with torch.no_grad():
+            (rgb0, op0, dep0, _), ri0, _ = Rm.render_rays(o, d, est, m0, white_bkgd=True, render_step_size=step, device=dev)
+            (rgb1, op1, dep1, _), ri1, _ = Rm.render_rays(o, d, est, m1, white_bkgd=True, render_step_size=step, device=dev)
+    n0, n1 = torch.bincount(ri0, minlength=R), torch.bincount(ri1, minlength=R)
+    dev_rgb, dev_op, dev_dep = (float((a - b).abs().max()) for a, b in ((rgb1, rgb0), (op1, op0), (dep1, dep0)))
+    STATS.setdefault("bf16_cull", {})[which] = {"max_abs_rgb": dev_rgb, "max_abs_opacity": dev_op, "max_abs_depth": dev_dep,
+                                               "kept_default": int(ri0.numel()), "kept_bf16_cull": int(ri1.numel()),
+                                               "rays_with_other_count": int((n0 != n1).sum())}
+    assert ri0.numel() > 10 * R
+    assert dev_rgb < 5e-5 and dev_op < 5e-5 and dev_dep < 5e-4, STATS["bf16_cull"][which]
+    assert int((n0 - n1).abs().sum()) <= 0.01 * ri0.numel(), STATS["bf16_cull"][which]
+
+
 def _relative_relu_margin(sd, x, d):
     """min over the ReLU layers of (smallest |pre-activation| of the sample / largest |pre-activation| of the LAYER over
     the batch): the shrunk students' layers live on very different scales (1e-4 .. 1), and a unit whose pre-activation
@@ -266,4 +300,4 @@ def test_zz_record_stats(dev, students):
     assert w3["wnorm_l1"] < 0.5 * w3["plain"], f"the regulariser shrank the weights ({w3})"
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out) and os.access(out, os.W_OK):
-        json.dump(STATS, open(os.path.join(out, "r03_trained_parity.json"), "w"), indent=1)
+        json.dump(STATS, open(os.path.join(out, "r04_trained_parity.json"), "w"), indent=1)
