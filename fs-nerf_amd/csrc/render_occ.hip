@@ -62,6 +62,10 @@ struct OccLds {
   uint16_t slotk[kCap];
 };
 
+// sample groups per wave of a tile (mlp.hip / render.hip): two in the single-pass modes of 256-wide networks
+template <int NT, int PREC>
+constexpr int groups_per_wave() { return ((PREC & 1) == 1 && NT == 8) ? 2 : 1; }
+
 constexpr int kOccLdsBytes = kRingBytes + (kAuxCapFloats + 96) * 4 + (int)sizeof(OccLds);
 static_assert(kOccLdsBytes <= 160 * 1024, "LDS budget");
 
@@ -219,15 +223,32 @@ __global__ __launch_bounds__(kThreads) void k_render_occ(OccKArgs k) {
     if (n_rays == 0) break;  // no ray left for this workgroup (uniform)
 
     // ------------------------------------------------------------ density pass + visibility (estimator.sampling)
+    // (single-pass modes of 256-wide networks: 256-sample tiles, two sample groups per wave sharing every A operand -
+    // mlp_tile2, the arithmetic per sample is mlp_tile's; this is what the opt-in bf16 visibility cull runs)
+    constexpr int NG = groups_per_wave<NT, PREC>(), TILE = 128 * NG;
     if (S.use_vis && n_cand > 0) {
-      for (int sub = 0; sub * 128 < n_cand; ++sub) {
-        const int idx = sub * 128 + wave * 16 + (lane & 15);
-        const int ic = min(idx, n_cand - 1);
-        const OccSrc src{FSN_SPAN(S.rays, 6 * FSN_AT(S.slotc, ic), 6), FSN_AT(S.t0c, ic), a.step};
-        float sigma, rgb[3];
-        st.begin_tile(nph_density);
-        mlp_tile<NT, PREC, false>(st, net, src, ring, sigma, rgb);
-        if (lane < 16 && idx < n_cand) FSN_AT(S.sigc, idx) = sigma;
+      for (int sub = 0; sub * TILE < n_cand; ++sub) {
+        if constexpr (NG == 1) {
+          const int idx = sub * 128 + wave * 16 + (lane & 15);
+          const int ic = min(idx, n_cand - 1);
+          const OccSrc src{FSN_SPAN(S.rays, 6 * FSN_AT(S.slotc, ic), 6), FSN_AT(S.t0c, ic), a.step};
+          float sigma, rgb[3];
+          st.begin_tile(nph_density);
+          mlp_tile<NT, PREC, false>(st, net, src, ring, sigma, rgb);
+          if (lane < 16 && idx < n_cand) FSN_AT(S.sigc, idx) = sigma;
+        } else {
+          const int idx = sub * TILE + wave * 32 + (lane & 15);
+          const int i0 = min(idx, n_cand - 1), i1 = min(idx + 16, n_cand - 1);
+          const OccSrc src0{FSN_SPAN(S.rays, 6 * FSN_AT(S.slotc, i0), 6), FSN_AT(S.t0c, i0), a.step};
+          const OccSrc src1{FSN_SPAN(S.rays, 6 * FSN_AT(S.slotc, i1), 6), FSN_AT(S.t0c, i1), a.step};
+          float sigma[2], rgb[2][3];
+          st.begin_tile(nph_density);
+          mlp_tile2<NT, PREC, false>(st, net, src0, src1, ring, sigma, rgb);
+          if (lane < 32) {  // lanes 0-15 write group 0, lanes 16-31 group 1 (every lane holds both results)
+            const int q = lane >> 4, iq = idx + 16 * q;
+            if (iq < n_cand) FSN_AT(S.sigc, iq) = sigma[q];
+          }
+        }
       }
       lds_barrier();
       // keep flags per ray: the arithmetic of k_visibility (occgrid.hip), one wave per ray
@@ -300,18 +321,37 @@ __global__ __launch_bounds__(kThreads) void k_render_occ(OccKArgs k) {
     }
     // ------------------------------------------------------------ full pass (rgb_sigma_fn) + packed integration
     const int n_kept = __builtin_amdgcn_readfirstlane(S.n_kept);
-    for (int sub = 0; sub * 128 < n_kept; ++sub) {
-      const int idx = sub * 128 + wave * 16 + (lane & 15);
-      const int ic = min(idx, n_kept - 1);
-      const OccSrc src{FSN_SPAN(S.rays, 6 * FSN_AT(S.slotk, ic), 6), FSN_AT(S.t0k, ic), a.step};
-      float sigma, rgb[3];
-      st.begin_tile(nph_full);
-      mlp_tile<NT, PREC, true>(st, net, src, ring, sigma, rgb);
-      if (lane < 16 && idx < n_kept) {
-        FSN_AT(S.sigk, idx) = sigma;
-        FSN_AT(S.rgbk, 3 * idx + 0) = rgb[0];
-        FSN_AT(S.rgbk, 3 * idx + 1) = rgb[1];
-        FSN_AT(S.rgbk, 3 * idx + 2) = rgb[2];
+    for (int sub = 0; sub * TILE < n_kept; ++sub) {
+      if constexpr (NG == 1) {
+        const int idx = sub * 128 + wave * 16 + (lane & 15);
+        const int ic = min(idx, n_kept - 1);
+        const OccSrc src{FSN_SPAN(S.rays, 6 * FSN_AT(S.slotk, ic), 6), FSN_AT(S.t0k, ic), a.step};
+        float sigma, rgb[3];
+        st.begin_tile(nph_full);
+        mlp_tile<NT, PREC, true>(st, net, src, ring, sigma, rgb);
+        if (lane < 16 && idx < n_kept) {
+          FSN_AT(S.sigk, idx) = sigma;
+          FSN_AT(S.rgbk, 3 * idx + 0) = rgb[0];
+          FSN_AT(S.rgbk, 3 * idx + 1) = rgb[1];
+          FSN_AT(S.rgbk, 3 * idx + 2) = rgb[2];
+        }
+      } else {
+        const int idx = sub * TILE + wave * 32 + (lane & 15);
+        const int i0 = min(idx, n_kept - 1), i1 = min(idx + 16, n_kept - 1);
+        const OccSrc src0{FSN_SPAN(S.rays, 6 * FSN_AT(S.slotk, i0), 6), FSN_AT(S.t0k, i0), a.step};
+        const OccSrc src1{FSN_SPAN(S.rays, 6 * FSN_AT(S.slotk, i1), 6), FSN_AT(S.t0k, i1), a.step};
+        float sigma[2], rgb[2][3];
+        st.begin_tile(nph_full);
+        mlp_tile2<NT, PREC, true>(st, net, src0, src1, ring, sigma, rgb);
+        if (lane < 32) {
+          const int q = lane >> 4, iq = idx + 16 * q;
+          if (iq < n_kept) {
+            FSN_AT(S.sigk, iq) = sigma[q];
+            FSN_AT(S.rgbk, 3 * iq + 0) = rgb[q][0];
+            FSN_AT(S.rgbk, 3 * iq + 1) = rgb[q][1];
+            FSN_AT(S.rgbk, 3 * iq + 2) = rgb[q][2];
+          }
+        }
       }
     }
     lds_barrier();
