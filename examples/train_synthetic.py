@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--iters", type=int, default=400)
     ap.add_argument("--hw", type=int, default=64)
     ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--cull-bf16", action="store_true",
+                    help="opt-in: the occupancy estimator's visibility cull in single-pass bf16 (NeRF.cull_precision; not the parity mode)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     hwf = (a.hw, a.hw, 0.5 * a.hw / math.tan(0.5 * 0.6911112))
@@ -65,6 +67,8 @@ def main():
     ro, rd, gt = torch.cat(ro), torch.cat(rd), torch.cat(gt)
 
     model = make_model(2, dev).train()
+    if a.cull_bf16:
+        model.cull_precision = "bf16"
     if a.estimator == "occgrid":
         estimator = OccGridEstimator(roi_aabb=torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5]), resolution=64, levels=1).to(dev)
     else:
