@@ -86,6 +86,7 @@ class FlatGrads:
         # backward of a network whose parameters live in this bucket ORs its per-call range word into it (device op),
         # the optimizer that owns the bucket hands it to its Adam launch and clears it.
         self.step_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._views = [self.view(i) for i in range(len(self.params))]  # the bucket's views, made once
         self.bind()
 
     def view(self, i: int) -> torch.Tensor:
@@ -95,9 +96,10 @@ class FlatGrads:
     def bind(self) -> None:
         """(Re)attach: gradients that autograd or the caller replaced are copied into the bucket, missing ones
         become zeros, and `p.grad` is pointed at the bucket again."""
-        for i, p in enumerate(self.params):
-            v = self.view(i)
+        for p, v in zip(self.params, self._views):
             g = p.grad
+            if g is v:  # still attached (the usual case: three calls per training step, 24 parameters each)
+                continue
             if g is None:
                 v.zero_()
             elif g.data_ptr() != v.data_ptr() or g.stride() != v.stride():
