@@ -387,7 +387,15 @@ def render_rays(rays_o: Tensor, rays_d: Tensor, estimator, model: nn.Module, tra
             out = fine(x, td)
             return out[..., :3], out[..., -1]
 
-        render_bkgd = white_bkgd * torch.ones((3,), device=device, requires_grad=train)  # rendering.py:86
+        # rendering.py:86 builds `white_bkgd * torch.ones((3,), device=device, requires_grad=train)`: the background's own
+        # requires_grad is what keeps loss.backward() legal when nothing else carries a gradient (an all-background batch,
+        # a frozen model).  Whenever the samples themselves carry one, the three values go to the compositor as launch
+        # arguments instead (a host tensor: no device round trip to read them, and none of the eight tiny launches that
+        # add the background and differentiate it with torch ops sit on the training step's host path).
+        if train and torch.is_grad_enabled() and not (needs_grad and ray_indices.numel() > 0):
+            render_bkgd = white_bkgd * torch.ones((3,), device=device, requires_grad=True)
+        else:
+            render_bkgd = torch.full((3,), float(white_bkgd))
         try:
             output = rendering(t_starts, t_ends, ray_indices, n_rays=len(rays_o), rgb_sigma_fn=rgb_sigma_fn,
                                render_bkgd=render_bkgd)
